@@ -1,0 +1,49 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def seed_all(s):
+    torch.manual_seed(s)
+    np.random.seed(s)
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def load_sd(module, npz, prefix):
+    """Load the arrays stored under '<prefix>/<state_dict key>' into module (strict)."""
+    sd = {}
+    for k in module.state_dict().keys():
+        a = npz[f"{prefix}/{k}"]
+        sd[k] = torch.from_numpy(np.asarray(a)).clone()
+    module.load_state_dict(sd, strict=True)
+    return module
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(np.asarray(a), dtype=torch.float64).flatten()
+    b = torch.as_tensor(np.asarray(b), dtype=torch.float64).flatten()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
