@@ -1,0 +1,182 @@
+"""bench.py -- BASELINE.json's metric on MI355X: generated videos/s (16-frame clips) of gen.sample_videos(32) on
+Rotated-MNIST-shaped synthetic data (batch 32, 16x1x28x28, ngf=ndf=64; configs[1]), plus G-step / D-step / full
+iteration milliseconds, at N = 1/2/4/8 GPUs (one process per GPU; weak scaling, 32 clips per GPU; gradients are
+all-reduced over RCCL once per optimiser step in the train-step timings).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...)
+
+A "step" of the headline metric is one sample_videos(32) call (host noise draw + H2D of 8.4 KB + pre-net + RK4 +
+decoder, train-mode BatchNorm, no_grad) -- exactly what the reference's "generated videos" are.  rank 0 prints ONE
+JSON line.  `roofline` is measured live with HIP events around repeated launches of the dominant kernel (the
+stride-2 ConvTranspose implicit GEMM) on the stream it runs on; `cpu_baseline` times the CPU oracle (a port of the
+reference path on stock torch CPU kernels) on this box's host cores for a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+B, T = 32, 16
+
+
+def _sync_all(distributed):
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _timed(fn, steps, warmup, distributed):
+    for _ in range(warmup):
+        fn()
+    _sync_all(distributed)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    _sync_all(distributed)
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def _kernel_roofline(gen, reps=30):
+    """Times each decoder GEMM launch on its own with HIP events on the launch stream and returns the roofline
+    object of the launch class that dominates the forward pass."""
+    import gan_ode_amd._lib as L
+    from gan_ode_amd.engine import stream_ptr
+    with torch.no_grad():
+        gen.sample_videos(B)                       # builds the plan and fills every buffer
+    plan = gen._pool.plans[(B, T, False)][0]
+    prog, _ = plan.stack._fwd[True]
+    rows = B * T
+    per_layer = []
+    igemms = [op for op in prog.ops if isinstance(op, L.IgemmOp)]
+    macs_per_row = [66 * 512 * 16, 512 * 256 * 16 * 4, 256 * 128 * 16 * 16, 128 * 64 * 16 * 64, 64 * 28 * 28]
+    names = ["convT0 66->512 (GEMM)", "convT1 512->256 k4s2", "convT2 256->128 k4s2", "convT3 128->64 k4s2",
+             "convT4 64->1 k1 + tanh"]
+    for op, macs, name in zip(igemms, macs_per_row, names):
+        st = stream_ptr()
+        for _ in range(3):
+            L.run_one(op, st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            L.run_one(op, st)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        flop = 2.0 * macs * rows
+        per_layer.append(dict(layer=name, ms=ms, gflop=flop / 1e9, tflops=flop / ms / 1e9))
+    dom = max(per_layer[1:4], key=lambda d: d["ms"])
+    roof = {"bound": "mfma", "kernel": "igemm_kernel (fp32 MFMA 32x32x2), " + dom["layer"],
+            "achieved": round(dom["tflops"], 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(dom["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "launch_ms": round(dom["ms"], 4), "algorithmic_gflop_per_launch": round(dom["gflop"], 2),
+            "per_layer": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in per_layer]}
+    return roof
+
+
+def _cpu_baseline(budget_s=15.0):
+    """The oracle (CPU port of the reference path on stock torch kernels) timed on the host cores: same workload,
+    bounded sample."""
+    from oracle import mocogan_ref as M
+    torch.manual_seed(0); np.random.seed(0)
+    gen, _, _ = M.build_mnist()
+    with torch.no_grad():
+        gen.sample_videos(B)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            gen.sample_videos(B)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 40:
+                break
+    return {"value": round(n * B / el, 2), "unit": "videos/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} calls of oracle sample_videos({B}) (ngf=64, T=16, train-mode BN, no_grad) in {el:.1f}s, "
+                      f"os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--train-steps", type=int, default=10, help="iterations for the G/D step timings")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    if distributed:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import gan_ode_amd as G
+    torch.manual_seed(1234 + rank); np.random.seed(1234 + rank)
+    gen, dv, di = G.build_mnist()
+    gen.cuda(); dv.cuda(); di.cuda()
+    if distributed:   # replicas start from rank 0's weights
+        for m in (gen, dv, di):
+            for t in list(m.parameters()) + list(m.buffers()):
+                dist.broadcast(t.data, src=0)
+
+    def sample():
+        with torch.no_grad():
+            gen.sample_videos(B)
+
+    dt = _timed(sample, a.steps, a.warmup, distributed)
+    vps = world * B * a.steps / dt
+
+    # G / D step and whole-iteration milliseconds (synthetic real data resident on the GPU)
+    tr = G.GanTrainer(gen, dv, di)
+    g = torch.Generator().manual_seed(99 + rank)
+    imgs = [torch.rand(B, 1, 28, 28, generator=g).cuda() for _ in range(2)]
+    vids = [torch.rand(B, T, 1, 28, 28, generator=g).cuda() for _ in range(2)]
+    k = max(1, a.train_steps)
+    wtr = max(1, min(3, k))
+    d_ms = _timed(lambda: (tr.d_image_step(imgs[0]), tr.d_video_step(vids[0])), k, wtr, distributed) / k * 1e3
+    g_ms = _timed(lambda: tr.g_step(B), k, wtr, distributed) / k * 1e3
+    it_ms = _timed(lambda: tr.step(imgs, vids), k, 1, distributed) / k * 1e3
+
+    if rank == 0:
+        roof = _kernel_roofline(gen)
+        cpu = None if a.no_cpu_baseline or distributed else _cpu_baseline()
+        line = {
+            "metric": "generated videos/sec (16-frame clips)", "value": round(vps, 2), "unit": "videos/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Rotated-MNIST MoCoGAN+ODE, gen.sample_videos(32): batch 32/GPU, 16x1x28x28, "
+                                   "ngf=ndf=64, rk4 (Kutta 3/8) on linspace(0,1,16) = 15 steps as the reference code "
+                                   "does, train-mode BN, random-init weights",
+                       "global_batch": world * B, "parallelism": f"dp{world}"},
+            "d_step_ms": round(d_ms, 3), "g_step_ms": round(g_ms, 3), "iteration_ms": round(it_ms, 3),
+            "train_videos_per_s": round(world * B / (it_ms / 1e3), 2),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,266 @@
+// elementwise.hip -- the HBM-bound companions of the GEMM kernels: BatchNorm statistics finalisation and backward,
+// BCE-with-logits, Adam(L2).  All reductions are fixed-order (partials -> one reducer), so results are
+// run-to-run reproducible.  Reference semantics: nn.BatchNorm2d/3d train mode (models/mocogan.py:76-85,143-156,
+// 202-212), nn.BCEWithLogitsLoss (mnist_moco_ode.py:89), torch.optim.Adam(weight_decay) (mnist_moco_ode.py:86-88).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm finalize
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const gode_bn_finalize_op a) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  __shared__ double red[2][256];
+  if (a.training) {
+    const int reps = a.ncols / a.C;
+    const int64_t items = (int64_t)a.rows * reps;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = tid; i < items; i += 256) {
+      const int64_t row = i / reps; const int rep = (int)(i - row * reps);
+      const float* p = a.stats + row * 2 * a.ncols + rep * a.C + c;
+      s1 += (double)p[0];
+      s2 += (double)p[a.ncols];
+    }
+    red[0][tid] = s1; red[1][tid] = s2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const double n = (double)a.count;
+      const double mean = red[0][0] / n;
+      double var = red[1][0] / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+      const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
+      const float sc = g * invstd;
+      a.mean[c] = (float)mean; a.invstd[c] = invstd;
+      a.scale[c] = sc; a.shift[c] = b - (float)mean * sc;
+      if (a.running_mean) {
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+      }
+      if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+    }
+  } else if (tid == 0) {
+    const float invstd = 1.f / sqrtf(a.running_var[c] + a.eps);
+    const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
+    const float sc = g * invstd;
+    if (a.mean) a.mean[c] = a.running_mean[c];
+    if (a.invstd) a.invstd[c] = invstd;
+    a.scale[c] = sc; a.shift[c] = b - a.running_mean[c] * sc;
+  }
+}
+
+extern "C" int gode_bn_finalize(const gode_bn_finalize_op* op, void* stream) {
+  if (!op || op->C <= 0 || !op->scale || !op->shift) return GODE_E_ARG;
+  if (op->training) {
+    if (!op->stats || !op->mean || !op->invstd || op->ncols % op->C != 0 || op->count <= 0) return GODE_E_ARG;
+  } else if (!op->running_mean || !op->running_var) return GODE_E_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(op->C), dim3(256), 0, (hipStream_t)stream, *op);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm + activation backward
+#define BNB_ROWS 1024
+
+__device__ __forceinline__ float gz_of(float g, float y, float sc, float sh, int act) {
+  if (act == GODE_ACT_TANH_OUT) return g * (1.f - y * y);
+  return g * gode_act_grad(y * sc + sh, act);
+}
+
+// partial[blk][2][C]: sum g_z, sum g_z * xhat   (C % 4 == 0, C/4 <= 256)
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const gode_bn_bwd_op a) {
+  const int C4 = a.C >> 2, tid = threadIdx.x;
+  const int rl = 256 / C4;            // row lanes
+  const int cl = tid % C4, rlane = tid / C4;
+  __shared__ float red[2][256][4];
+  f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  if (rlane < rl) {
+    const int c = cl * 4;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c), sh = *reinterpret_cast<const f32x4*>(a.shift + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + c), is = *reinterpret_cast<const f32x4*>(a.invstd + c);
+    const int64_t r0 = (int64_t)blockIdx.x * BNB_ROWS;
+    const int64_t r1 = r0 + BNB_ROWS < a.M ? r0 + BNB_ROWS : a.M;
+    for (int64_t r = r0 + rlane; r < r1; r += rl) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + r * a.C + c);
+      const f32x4 y = *reinterpret_cast<const f32x4*>(a.y + r * a.C + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gz = gz_of(g[e], y[e], sc[e], sh[e], a.act);
+        s1[e] += gz;
+        s2[e] += gz * ((y[e] - mu[e]) * is[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[0][tid][e] = s1[e]; red[1][tid][e] = s2[e]; }
+  __syncthreads();
+  if (tid < C4) {
+    f32x4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
+    for (int j = 0; j < rl; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { t1[e] += red[0][j * C4 + tid][e]; t2[e] += red[1][j * C4 + tid][e]; }
+    float* dst = a.work + (int64_t)blockIdx.x * 2 * a.C;
+    *reinterpret_cast<f32x4*>(dst + tid * 4) = t1;
+    *reinterpret_cast<f32x4*>(dst + a.C + tid * 4) = t2;
+  }
+}
+
+// one block per channel: reduce partials, write dgamma/dbeta and the three apply coefficients
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const gode_bn_bwd_op a, int rows) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  __shared__ double red[2][256];
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = tid; r < rows; r += 256) {
+    s1 += (double)a.work[(int64_t)r * 2 * a.C + c];
+    s2 += (double)a.work[(int64_t)r * 2 * a.C + a.C + c];
+  }
+  red[0][tid] = s1; red[1][tid] = s2;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float dbeta = (float)red[0][0], dgamma = (float)red[1][0];
+    if (a.dbeta) a.dbeta[c] = a.accumulate ? a.dbeta[c] + dbeta : dbeta;
+    if (a.dgamma) a.dgamma[c] = a.accumulate ? a.dgamma[c] + dgamma : dgamma;
+    const double invM = 1.0 / (double)a.M;
+    const double g = a.gamma ? (double)a.gamma[c] : 1.0, is = (double)a.invstd[c], mu = (double)a.mean[c];
+    const double k = g * is;
+    float* coef = a.work + (int64_t)rows * 2 * a.C;
+    coef[c] = (float)k;                                                              // * g_z
+    coef[a.C + c] = (float)(-k * is * red[1][0] * invM);                             // * y
+    coef[2 * a.C + c] = (float)(-k * red[0][0] * invM + k * is * red[1][0] * invM * mu);  // constant
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const gode_bn_bwd_op a, int rows) {
+  const int64_t n4 = a.M * a.C / 4;
+  const float* coef = a.work + (int64_t)rows * 2 * a.C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)((i * 4) % a.C);
+    f32x4 g = *reinterpret_cast<const f32x4*>(a.g + i * 4);
+    const f32x4 y = *reinterpret_cast<const f32x4*>(a.y + i * 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c), sh = *reinterpret_cast<const f32x4*>(a.shift + c);
+    const f32x4 cA = *reinterpret_cast<const f32x4*>(coef + c), cB = *reinterpret_cast<const f32x4*>(coef + a.C + c),
+                cC = *reinterpret_cast<const f32x4*>(coef + 2 * a.C + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = cA[e] * gz_of(g[e], y[e], sc[e], sh[e], a.act) + cB[e] * y[e] + cC[e];
+    *reinterpret_cast<f32x4*>(a.g + i * 4) = g;
+  }
+}
+
+// no BatchNorm: g *= act'(y) (or tanh-from-output), any C
+__global__ void __launch_bounds__(256) act_bwd_kernel(float* g, const float* y, int64_t n, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    g[i] = gz_of(g[i], y[i], 1.f, 0.f, act);
+}
+
+extern "C" int64_t gode_bn_bwd_work_size(int64_t M, int32_t C) {
+  const int64_t rows = (M + BNB_ROWS - 1) / BNB_ROWS;
+  return rows * 2 * C + 3 * (int64_t)C;
+}
+
+static int ew_blocks(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+extern "C" int gode_bn_bwd(const gode_bn_bwd_op* op, void* stream) {
+  if (!op || !op->g || !op->y || op->M <= 0 || op->C <= 0) return GODE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (!op->mean) {
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(op->M * op->C)), dim3(256), 0, st, op->g, op->y,
+                       op->M * op->C, op->act);
+    GODE_LAUNCH_CHECK();
+    return 0;
+  }
+  if (op->C % 4 != 0 || op->C / 4 > 256 || !op->invstd || !op->scale || !op->shift || !op->work) return GODE_E_ARG;
+  const int rows = (int)((op->M + BNB_ROWS - 1) / BNB_ROWS);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rows), dim3(256), 0, st, *op);
+  GODE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(op->C), dim3(256), 0, st, *op, rows);
+  GODE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(op->M * op->C / 4)), dim3(256), 0, st, *op, rows);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BCE with logits against a constant target, mean reduction (single block: n is a few thousand at most)
+__global__ void __launch_bounds__(256) bce_kernel(const gode_bce_op a) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  double s = 0.0;
+  const float inv = 1.f / (float)a.n;
+  for (int64_t i = tid; i < a.n; i += 256) {
+    const float x = a.logits[i];
+    const float l = fmaxf(x, 0.f) - x * a.target + log1pf(expf(-fabsf(x)));
+    s += (double)l;
+    if (a.grad) {
+      const float sig = 1.f / (1.f + expf(-x));
+      a.grad[i] = a.gscale * (sig - a.target) * inv;
+    }
+  }
+  red[tid] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (tid < k) red[tid] += red[tid + k];
+    __syncthreads();
+  }
+  if (tid == 0 && a.loss) {
+    const float v = (float)(red[0] / (double)a.n);
+    *a.loss = a.accumulate ? *a.loss + v : v;
+  }
+}
+
+extern "C" int gode_bce_logits(const gode_bce_op* op, void* stream) {
+  if (!op || !op->logits || op->n <= 0) return GODE_E_ARG;
+  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *op);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Adam with L2-coupled weight decay (operation order of torch.optim.Adam's single-tensor path)
+__global__ void __launch_bounds__(256) adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float b1,
+                                                   float b2, float eps, float wd, float gscale, float step_size,
+                                                   float bc2_sqrt) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float pi = p[i];
+    const float gi = g[i] * gscale + wd * pi;
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+extern "C" int gode_adam_l2(const gode_adam_op* op, void* stream) {
+  if (!op || !op->p || !op->g || !op->m || !op->v || op->n <= 0 || op->step < 1) return GODE_E_ARG;
+  const double bc1 = 1.0 - pow((double)op->beta1, (double)op->step);
+  const double bc2 = 1.0 - pow((double)op->beta2, (double)op->step);
+  const float step_size = (float)((double)op->lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(op->n)), dim3(256), 0, (hipStream_t)stream, op->p, op->g, op->m,
+                     op->v, op->n, op->beta1, op->beta2, op->eps, op->weight_decay, op->gscale, step_size, bc2_sqrt);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void __launch_bounds__(256) scale_kernel(float* out, const float* a, int64_t n, float alpha, int acc) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = acc ? out[i] + a[i] * alpha : a[i] * alpha;
+}
+
+extern "C" int gode_scale(float* out, const float* a, int64_t n, float alpha, int accumulate, void* stream) {
+  if (!out || !a || n <= 0) return GODE_E_ARG;
+  hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, out, a, n, alpha, accumulate);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}

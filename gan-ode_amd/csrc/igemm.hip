@@ -1,0 +1,361 @@
+// igemm.hip -- implicit-GEMM convolution for gfx950 on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// One kernel serves Conv2d/Conv3d forward (FPROP), their input gradients and the ConvTranspose2d forward
+// (DGRAD, one sub-GEMM per stride phase so that no MFMA is spent on structurally-zero taps), and the plain GEMM of
+// the generator's first layer (FULLK).  Reference layers: models/mocogan.py:72-89,138-159,200-215,
+// models/mocogan_ode.py:66-84.
+//
+// Data flow per workgroup (256 threads = 4 waves, BMxBN output tile, K slabs of 32):
+//   global (channels-last, 128-B rows)  --float4 gathers + fused BN/activation of the previous layer-->  registers
+//   --ds_write_b128-->  LDS [row][36] (pad 4 => conflict-free ds_read_b128)  --> 32x32x2 MFMA, 2x2 tiles / wave
+//   slab s+1 is fetched into registers while slab s is multiplied (two LDS buffers, one barrier per slab).
+// MFMA k-index trick: lane half h supplies k = 4h+j in step j, so one ds_read_b128 feeds four MFMAs.
+// Epilogue: raw (or tanh) store, 128-B coalesced along channels, plus deterministic per-column partial sums for
+// train-mode BatchNorm (no atomics).
+#include "common.h"
+#include "conv_geom.h"
+
+struct IgemmArgs {
+  IgemmGeom G;
+  const float* src;
+  const float* w;
+  float* out;
+  const float* scale;
+  const float* shift;
+  float* stats;
+  int32_t gsN, gsD, gsH, gsW, gsC;
+  int32_t act, epilogue;
+};
+
+template <int WM, int WN, int TM, int TN, bool VEC>
+__global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const IgemmArgs a) {
+  constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32, LDK = 36;
+  constexpr int RPP = NT / 8;  // tile rows covered by one loader pass (8 threads x float4 per 32-wide row)
+  constexpr int AP = BM / RPP, BP = BN / RPP;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/loader mismatch");
+  constexpr int BUF = (BM + BN) * LDK;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BUF + BM * 5];
+  int* rowinfo = reinterpret_cast<int*>(smem + 2 * BUF);  // [BM][4]: base, bd, bh, bw
+  int* outoff = rowinfo + BM * 4;                          // [BM]
+
+  const PhaseGeom& P = a.G.ph[blockIdx.z];
+  const int mblk = blockIdx.x, nblk = blockIdx.y;
+  if (mblk * BM >= P.M) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int Cg = a.G.Cg, Ncols = a.G.Ncols;
+
+  for (int r = tid; r < BM; r += NT) {
+    const int m = mblk * BM + r;
+    int base = -1, bd = 0, bh = 0, bw = 0, oo = -1;
+    if (m < P.M) {
+      const int qw = m % P.Mw; int t = m / P.Mw;
+      const int qh = t % P.Mh; t /= P.Mh;
+      const int qd = t % P.Md; const int img = t / P.Md;
+      base = img * a.gsN;
+      bd = qd * a.G.Sd + P.Od; bh = qh * a.G.Sh + P.Oh; bw = qw * a.G.Sw + P.Ow;
+      oo = (((img * a.G.Xd + qd * a.G.OSd + P.Pd) * a.G.Xh + qh * a.G.OSh + P.Ph) * a.G.Xw + qw * a.G.OSw + P.Pw) *
+           Ncols;
+    }
+    rowinfo[r * 4 + 0] = base; rowinfo[r * 4 + 1] = bd; rowinfo[r * 4 + 2] = bh; rowinfo[r * 4 + 3] = bw;
+    outoff[r] = oo;
+  }
+  __syncthreads();
+
+  int rbase[AP], rbd[AP], rbh[AP], rbw[AP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    const int r = (tid >> 3) + RPP * i;
+    rbase[i] = rowinfo[r * 4 + 0]; rbd[i] = rowinfo[r * 4 + 1]; rbh[i] = rowinfo[r * 4 + 2]; rbw[i] = rowinfo[r * 4 + 3];
+  }
+  const int kchunk = (tid & 7) * 4;
+  const float* wp = a.w + P.w_off;
+  const int J = a.G.J, Gd = a.G.Gd, Gh = a.G.Gh, Gw = a.G.Gw;
+  const int nslab = (P.Kp + 31) >> 5;
+
+  f32x4 ra[AP], rb[BP], sc4, sh4;
+  unsigned amask = 0;
+  const bool xf = a.scale != nullptr;
+
+  auto fetch = [&](int slab) {
+    const int kk = slab * 32 + kchunk;
+    amask = 0;
+    sc4 = f32x4{1.f, 1.f, 1.f, 1.f}; sh4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (VEC) {
+      if (kk < P.K) {
+        const int tap = kk / Cg, c = kk - tap * Cg;
+        const int jw = tap % P.Tw, t2 = tap / P.Tw, jh = t2 % P.Th, jd = t2 / P.Th;
+        if (xf) { sc4 = *reinterpret_cast<const f32x4*>(a.scale + c); sh4 = *reinterpret_cast<const f32x4*>(a.shift + c); }
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+          const int id = rbd[i] + J * jd, ih = rbh[i] + J * jh, iw = rbw[i] + J * jw;
+          if (rbase[i] >= 0 && (unsigned)id < (unsigned)Gd && (unsigned)ih < (unsigned)Gh && (unsigned)iw < (unsigned)Gw) {
+            ra[i] = *reinterpret_cast<const f32x4*>(a.src + rbase[i] + id * a.gsD + ih * a.gsH + iw * a.gsW + c);
+            amask |= 1u << i;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = kk + e;
+        if (k < P.K) {
+          const int tap = k / Cg, c = k - tap * Cg;
+          const int jw = tap % P.Tw, t2 = tap / P.Tw, jh = t2 % P.Th, jd = t2 / P.Th;
+          if (xf) { sc4[e] = a.scale[c]; sh4[e] = a.shift[c]; }
+#pragma unroll
+          for (int i = 0; i < AP; ++i) {
+            const int id = rbd[i] + J * jd, ih = rbh[i] + J * jh, iw = rbw[i] + J * jw;
+            if (rbase[i] >= 0 && (unsigned)id < (unsigned)Gd && (unsigned)ih < (unsigned)Gh && (unsigned)iw < (unsigned)Gw) {
+              ra[i][e] = a.src[rbase[i] + id * a.gsD + ih * a.gsH + iw * a.gsW + c * a.gsC];
+              amask |= 1u << (i * 4 + e);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const int n = nblk * BN + (tid >> 3) + RPP * i;
+      if (n < Ncols && kk < P.Kp) rb[i] = *reinterpret_cast<const f32x4*>(wp + (int64_t)n * P.Kp + kk);
+      else rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  auto stage = [&](int buf) {
+    float* As = smem + buf * BUF;
+    float* Bs = As + BM * LDK;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = VEC ? ((amask >> i) & 1u) : ((amask >> (i * 4 + e)) & 1u);
+        float t = ra[i][e];
+        if (xf) t = gode_act(t * sc4[e] + sh4[e], a.act);
+        else t = gode_act(t, a.act);
+        v[e] = ok ? t : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(As + ((tid >> 3) + RPP * i) * LDK + kchunk) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(Bs + ((tid >> 3) + RPP * i) * LDK + kchunk) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  fetch(0);
+  stage(0);
+  __syncthreads();
+
+  const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
+  for (int s = 0; s < nslab; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nslab) fetch(s + 1);
+    const float* As = smem + buf * BUF + (wm * TM * 32 + frag_row) * LDK + frag_k;
+    const float* Bs = smem + buf * BUF + BM * LDK + (wn * TN * 32 + frag_row) * LDK + frag_k;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDK + kg * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDK + kg * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < nslab) stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int ccol = lane & 31, crow = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = nblk * BN + (wn * TN + j) * 32 + ccol;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + crow;
+        const int oo = outoff[row];
+        if (oo >= 0 && col < Ncols) {
+          float v = acc[i][j][r];
+          if (a.epilogue == GODE_EPI_TANH) v = tanhf(v);
+          a.out[oo + col] = v;
+        }
+      }
+    }
+
+  if (a.stats != nullptr) {
+    float* sred = smem;  // [WM][BN][2]; all waves are past the last barrier of the main loop
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; s1 += v; s2 += v * v; }
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lane < 32) {
+        const int c = (wn * TN + j) * 32 + lane;
+        sred[(wm * BN + c) * 2 + 0] = s1;
+        sred[(wm * BN + c) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += NT) {
+      const int col = nblk * BN + c;
+      if (col < Ncols) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { s1 += sred[(w * BN + c) * 2 + 0]; s2 += sred[(w * BN + c) * 2 + 1]; }
+        float* dst = a.stats + (int64_t)(P.row0 + mblk) * 2 * Ncols;
+        dst[col] = s1;
+        dst[Ncols + col] = s2;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+enum { TILE_128x128 = 1, TILE_128x64 = 2, TILE_128x32 = 3, TILE_64x64 = 4 };
+
+static int tile_bm(int tile) { return tile == TILE_64x64 ? 64 : 128; }
+static int tile_bn(int tile) { return tile == TILE_128x128 ? 128 : tile == TILE_128x32 ? 32 : 64; }
+
+static int pick_tile(const IgemmGeom& G, int requested) {
+  if (requested >= TILE_128x128 && requested <= TILE_64x64) return requested;
+  if (G.Ncols <= 32) return TILE_128x32;
+  if (G.Ncols <= 64) return TILE_128x64;
+  int64_t blocks = 0;
+  for (int i = 0; i < G.nphase; ++i) blocks += (int64_t)gode_ceil_div(G.ph[i].M, 128) * gode_ceil_div(G.Ncols, 128);
+  return blocks >= 192 ? TILE_128x128 : TILE_64x64;
+}
+
+static int prepare(const gode_igemm_op* op, IgemmArgs* A, int* tile, int* max_mblk, int* rows) {
+  int rc = gode_build_igemm_geom(op->g, op->dir, &A->G);
+  if (rc) return rc;
+  *tile = pick_tile(A->G, op->tile);
+  const int bm = tile_bm(*tile);
+  int r0 = 0, mx = 0;
+  for (int i = 0; i < A->G.nphase; ++i) {
+    A->G.ph[i].row0 = r0;
+    const int mb = gode_ceil_div(A->G.ph[i].M, bm);
+    r0 += mb;
+    if (mb > mx) mx = mb;
+  }
+  *max_mblk = mx;
+  *rows = r0;
+  return 0;
+}
+
+extern "C" int gode_igemm_stats_rows(const gode_igemm_op* op) {
+  IgemmArgs A; int tile, mx, rows;
+  int rc = prepare(op, &A, &tile, &mx, &rows);
+  return rc ? rc : rows;
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch(const IgemmArgs& A, bool vec, int max_mblk, hipStream_t st) {
+  constexpr int BN = WN * TN * 32;
+  dim3 grid(max_mblk, gode_ceil_div(A.G.Ncols, BN), A.G.nphase), block(WM * WN * 64);
+  if (vec) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true>), grid, block, 0, st, A);
+  else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false>), grid, block, 0, st, A);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
+  if (!op || !op->src || !op->wpack || !op->out) return GODE_E_ARG;
+  IgemmArgs A;
+  int tile, max_mblk, rows;
+  int rc = prepare(op, &A, &tile, &max_mblk, &rows);
+  if (rc) return rc;
+  if (max_mblk == 0) return 0;
+  const IgemmGeom& G = A.G;
+  int64_t gs[5];
+  if (gode_strides_are_channels_last(op->gs)) {
+    gs[4] = 1; gs[3] = G.Cg; gs[2] = (int64_t)G.Gw * gs[3]; gs[1] = (int64_t)G.Gh * gs[2]; gs[0] = (int64_t)G.Gd * gs[1];
+  } else {
+    for (int i = 0; i < 5; ++i) gs[i] = op->gs[i];
+  }
+  // 32-bit offset arithmetic inside the kernel: the gathered span and the output must stay below 2^31 elements
+  int64_t span = 1 + (int64_t)(op->g.N - 1) * gs[0] + (int64_t)(G.Gd - 1) * gs[1] + (int64_t)(G.Gh - 1) * gs[2] +
+                 (int64_t)(G.Gw - 1) * gs[3] + (int64_t)(G.Cg - 1) * gs[4];
+  int64_t outn = (int64_t)op->g.N * G.Xd * G.Xh * G.Xw * G.Ncols;
+  for (int i = 0; i < 5; ++i) if (gs[i] < 0) return GODE_E_ARG;
+  if (span >= (1ll << 31) || outn >= (1ll << 31)) return GODE_E_SHAPE;
+  A.src = op->src; A.w = op->wpack; A.out = op->out; A.scale = op->scale; A.shift = op->shift; A.stats = op->stats;
+  A.gsN = (int)gs[0]; A.gsD = (int)gs[1]; A.gsH = (int)gs[2]; A.gsW = (int)gs[3]; A.gsC = (int)gs[4];
+  A.act = op->act; A.epilogue = op->epilogue;
+  if ((op->scale == nullptr) != (op->shift == nullptr)) return GODE_E_ARG;
+  const bool vec = gs[4] == 1 && (G.Cg % 4) == 0 && (gs[0] % 4) == 0 && (gs[1] % 4) == 0 && (gs[2] % 4) == 0 &&
+                   (gs[3] % 4) == 0 && ((uintptr_t)op->src % 16) == 0 &&
+                   (op->scale == nullptr || ((uintptr_t)op->scale % 16 == 0 && (uintptr_t)op->shift % 16 == 0));
+  if (((uintptr_t)op->wpack % 16) != 0) return GODE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  switch (tile) {
+    case TILE_128x128: return launch<2, 2, 2, 2>(A, vec, max_mblk, st);
+    case TILE_128x64: return launch<2, 2, 2, 1>(A, vec, max_mblk, st);
+    case TILE_128x32: return launch<4, 1, 1, 1>(A, vec, max_mblk, st);
+    case TILE_64x64: return launch<2, 2, 1, 1>(A, vec, max_mblk, st);
+  }
+  return GODE_E_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight packing: canonical W[co][ci][taps] -> per-phase panels Bp[n][Kp] (k contiguous, zero padded)
+struct PackArgs {
+  IgemmGeom G;
+  gode_conv_geom g;
+  int dir;
+  const float* w;
+  float* wp;
+  const int32_t* co_perm;
+};
+
+__global__ void pack_kernel(const PackArgs a) {
+  const PhaseGeom& P = a.G.ph[blockIdx.z];
+  const int64_t total = (int64_t)a.G.Ncols * P.Kp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / P.Kp), k = (int)(i - (int64_t)n * P.Kp);
+    const int64_t src = gode_pack_source(a.g, a.dir, a.G, P, n, k, a.co_perm);
+    a.wp[P.w_off + i] = src >= 0 ? a.w[src] : 0.f;
+  }
+}
+
+extern "C" int64_t gode_pack_size(const gode_conv_geom* g, int dir) {
+  IgemmGeom G;
+  int rc = gode_build_igemm_geom(*g, dir, &G);
+  return rc ? rc : gode_pack_floats(G);
+}
+
+extern "C" int gode_pack_weights(const gode_conv_geom* g, int dir, const float* w, float* wpack, const int32_t* co_perm,
+                                 int32_t co_canon, void* stream) {
+  (void)co_canon;
+  if (!g || !w || !wpack) return GODE_E_ARG;
+  PackArgs A;
+  int rc = gode_build_igemm_geom(*g, dir, &A.G);
+  if (rc) return rc;
+  A.g = *g; A.dir = dir; A.w = w; A.wp = wpack; A.co_perm = co_perm;
+  int64_t mx = 0;
+  for (int i = 0; i < A.G.nphase; ++i) { int64_t t = (int64_t)A.G.Ncols * A.G.ph[i].Kp; if (t > mx) mx = t; }
+  if (mx == 0) return 0;
+  int blocks = (int)((mx + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks, 1, A.G.nphase), dim3(256), 0, (hipStream_t)stream, A);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}

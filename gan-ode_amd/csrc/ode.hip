@@ -1,0 +1,270 @@
+// ode.hip -- the motion-latent Neural-ODE of MoCoGAN-ODE fused into one launch each way.
+//
+// Reference arithmetic: models/mocogan_ode.py:6-17 (ODEFunc: Linear(16,16)-Tanh-Linear(16,16)), :123-129 (pre-net
+// Linear(16,64)-LReLU-Linear(64,16)-LReLU), :133-148 (odeint_adjoint(..., linspace(0,1,T), method='rk4')), and
+// torchdiffeq's fixed-grid rk4 (Kutta 3/8 rule) + continuous-adjoint backward (restated in oracle/ode_ref.py).
+// In PyTorch one solve is ~360 dependent micro-kernels; here it is one wave-resident loop.
+//
+// Mapping: one wave = 16 trajectories.  Every 16x16 mat-vec batch is exactly one v_mfma_f32_16x16x4_f32 tile
+// computed TRANSPOSED (D = W * Y^T): lane (s = lane&15, g = lane>>4) ends up holding features 4g..4g+3 of
+// trajectory s in its 4 accumulator registers.  Because the MFMA k order is free as long as A and B agree, step r
+// of the next product takes k = 4g+r: the accumulator registers of one product are fed straight back as the B
+// operand of the next and the weights are pre-loaded in that k order -- no cross-lane traffic in the whole solve.
+// Only the parameter-gradient outer products of the adjoint pass (sum over trajectories) need a transpose; it goes
+// through a 1.25 KB per-matrix LDS tile and is again an MFMA (k = trajectory).
+#include "common.h"
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ f32x4 matvec(const f32x4 w, const f32x4 x, f32x4 c) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c = MFMA16(w[r], x[r], c);
+  return c;
+}
+__device__ __forceinline__ f32x4 tanh4(const f32x4 u) { return f32x4{tanhf(u[0]), tanhf(u[1]), tanhf(u[2]), tanhf(u[3])}; }
+__device__ __forceinline__ f32x4 lrelu4(const f32x4 u) {
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = u[r] > 0.f ? u[r] : 0.2f * u[r];
+  return o;
+}
+__device__ __forceinline__ f32x4 lrelu_grad4(const f32x4 pre, const f32x4 gr) {
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = pre[r] > 0.f ? gr[r] : 0.2f * gr[r];
+  return o;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) ode_fwd_kernel(const gode_ode_fwd_op a) {
+  const int l = threadIdx.x, s = l & 15, g = l >> 4;
+  const int n0 = blockIdx.x * 16, n = n0 + s;
+  const bool valid = n < a.N;
+  const int T = a.T;
+
+  f32x4 y = valid ? ld4(a.x + n * 16 + 4 * g) : zero4();
+  if (a.prenet) {
+    f32x4 acc = ld4(a.p.bb + 4 * g);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      f32x4 h = matvec(ld4(a.p.Wa + (16 * m + s) * 16 + 4 * g), y, ld4(a.p.ba + 16 * m + 4 * g));
+      acc = matvec(ld4(a.p.Wb + s * 64 + 16 * m + 4 * g), lrelu4(h), acc);
+    }
+    y = lrelu4(acc);
+  }
+  const f32x4 w1 = ld4(a.p.W1 + s * 16 + 4 * g), w2 = ld4(a.p.W2 + s * 16 + 4 * g);
+  const f32x4 b1 = ld4(a.p.b1 + 4 * g), b2 = ld4(a.p.b2 + 4 * g);
+  auto f = [&](const f32x4 yy) { return matvec(w2, tanh4(matvec(w1, yy, b1)), b2); };
+
+  const int tsel = (a.sel_t && valid) ? a.sel_t[n] : -1;
+  auto emit = [&](int t) {
+    if (!valid) return;
+    if (a.traj) *reinterpret_cast<f32x4*>(a.traj + ((int64_t)n * T + t) * 16 + 4 * g) = y;
+    if (a.sel_t == nullptr) *reinterpret_cast<f32x4*>(a.z + ((int64_t)n * T + t) * 72 + 4 * g) = y;
+    else if (t == tsel) *reinterpret_cast<f32x4*>(a.z + (int64_t)n * 72 + 4 * g) = y;
+  };
+  emit(0);
+  const float third = 1.0f / 3.0f;
+  for (int j = 0; j + 1 < T; ++j) {
+    const float dt = a.dt[j] / (float)a.substeps;
+    for (int ss = 0; ss < a.substeps; ++ss) {
+      const f32x4 k1 = f(y);
+      const f32x4 k2 = f(y + dt * k1 * third);
+      const f32x4 k3 = f(y + dt * (k2 - k1 * third));
+      const f32x4 k4 = f(y + dt * (k1 - k2 + k3));
+      y = y + (k1 + 3.f * (k2 + k3) + k4) * dt * 0.125f;
+    }
+    emit(j + 1);
+  }
+
+  // content columns 16..65 (broadcast over the T rows of a trajectory) and zero pad 66..71
+  if (a.content) {
+    const int rows_per = a.sel_t ? 1 : T;
+    const int total = 16 * rows_per * 56;
+    for (int i = l; i < total; i += 64) {
+      const int rr = i / 56, cc = i - rr * 56;
+      const int ns = rr / rows_per, tt = rr - ns * rows_per;
+      const int nn = n0 + ns;
+      if (nn < a.N) {
+        const float v = cc < 50 ? a.content[(int64_t)nn * 50 + cc] : 0.f;
+        a.z[((int64_t)nn * rows_per + tt) * 72 + 16 + cc] = v;
+      }
+    }
+  }
+}
+
+extern "C" int gode_ode_fwd(const gode_ode_fwd_op* op, void* stream) {
+  if (!op || !op->x || !op->z || !op->dt || op->N <= 0 || op->T < 1 || op->substeps < 1) return GODE_E_ARG;
+  if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2) return GODE_E_ARG;
+  if (op->prenet && (!op->p.Wa || !op->p.ba || !op->p.Wb || !op->p.bb)) return GODE_E_ARG;
+  hipLaunchKernelGGL(ode_fwd_kernel, dim3((op->N + 15) / 16), dim3(64), 0, (hipStream_t)stream, *op);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// adjoint backward
+#define OFF_WA 0
+#define OFF_BA 1024
+#define OFF_WB 1088
+#define OFF_BB 2112
+#define OFF_W1 2128
+#define OFF_B1 2384
+#define OFF_W2 2400
+#define OFF_B2 2656
+#define LDT 20  // LDS row stride (floats) of a 16x16 transpose tile: conflict-free b128 writes / b32 reads
+
+// sum over the 16 trajectories of a wave (lanes sharing g)
+__device__ __forceinline__ f32x4 sum_over_samples(f32x4 v) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    v[r] += __shfl_xor(v[r], 1);
+    v[r] += __shfl_xor(v[r], 2);
+    v[r] += __shfl_xor(v[r], 4);
+    v[r] += __shfl_xor(v[r], 8);
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(64) ode_bwd_kernel(const gode_ode_bwd_op a) {
+  __shared__ __attribute__((aligned(16))) float tile[4][16 * LDT];
+  const int l = threadIdx.x, s = l & 15, g = l >> 4;
+  const int n0 = blockIdx.x * 16, n = n0 + s;
+  const bool valid = n < a.N;
+  const int T = a.T;
+  float* part = a.work + (int64_t)blockIdx.x * GODE_ODE_NPARAM;
+
+  const f32x4 w1 = ld4(a.p.W1 + s * 16 + 4 * g), w2 = ld4(a.p.W2 + s * 16 + 4 * g);
+  const f32x4 b1 = ld4(a.p.b1 + 4 * g), b2 = ld4(a.p.b2 + 4 * g);
+  f32x4 w1t, w2t;  // transposed operands: (W^T)[s][4g+r] = W[4g+r][s]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { w1t[r] = a.p.W1[(4 * g + r) * 16 + s]; w2t[r] = a.p.W2[(4 * g + r) * 16 + s]; }
+
+  // dst += sum over trajectories of P[s][i] * Q[s][j]; P, Q given in D layout (lane (s,g) holds cols 4g..4g+3).
+  // result in D layout: lane (j = lane&15, g) register r = dst[4g + r][j]
+  auto outer = [&](f32x4 dst, const f32x4 P, const f32x4 Q) {
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(&tile[0][s * LDT + 4 * g]) = P;
+    *reinterpret_cast<f32x4*>(&tile[1][s * LDT + 4 * g]) = Q;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst = MFMA16(tile[0][(4 * g + r) * LDT + s], tile[1][(4 * g + r) * LDT + s], dst);
+    return dst;
+  };
+
+  f32x4 gW1 = zero4(), gW2 = zero4(), gb1 = zero4(), gb2 = zero4();
+  const int tsel = (a.sel_t && valid) ? a.sel_t[n] : -1;
+  auto upstream = [&](int t) {
+    if (!valid) return zero4();
+    if (a.sel_t == nullptr) return ld4(a.gz + ((int64_t)n * T + t) * 72 + 4 * g);
+    return t == tsel ? ld4(a.gz + (int64_t)n * 72 + 4 * g) : zero4();
+  };
+
+  f32x4 adj = upstream(T - 1);
+  f32x4 ky, ka;
+  // one stage of the reversed augmented dynamics at (ys, as); c = RK weight * dt/8 for the parameter integrals
+  auto stage = [&](const f32x4 ys, const f32x4 as, float c) {
+    const f32x4 h = tanh4(matvec(w1, ys, b1));
+    const f32x4 fv = matvec(w2, h, b2);
+    const f32x4 v = matvec(w2t, as, zero4());
+    const f32x4 du = v * (1.f - h * h);
+    ka = matvec(w1t, du, zero4());
+    ky = -fv;
+    const f32x4 ca = c * as, cdu = c * du;
+    gb2 += ca; gb1 += cdu;
+    gW2 = outer(gW2, ca, h);
+    gW1 = outer(gW1, cdu, ys);
+  };
+
+  const float third = 1.0f / 3.0f;
+  for (int i = T - 1; i >= 1; --i) {
+    f32x4 y = valid ? ld4(a.traj + ((int64_t)n * T + i) * 16 + 4 * g) : zero4();
+    const float dt = a.dt[i - 1] / (float)a.substeps;
+    for (int ss = 0; ss < a.substeps; ++ss) {
+      stage(y, adj, dt * 0.125f);
+      const f32x4 ky1 = ky, ka1 = ka;
+      stage(y + dt * ky1 * third, adj + dt * ka1 * third, 3.f * dt * 0.125f);
+      const f32x4 ky2 = ky, ka2 = ka;
+      stage(y + dt * (ky2 - ky1 * third), adj + dt * (ka2 - ka1 * third), 3.f * dt * 0.125f);
+      const f32x4 ky3 = ky, ka3 = ka;
+      stage(y + dt * (ky1 - ky2 + ky3), adj + dt * (ka1 - ka2 + ka3), dt * 0.125f);
+      y = y + (ky1 + 3.f * (ky2 + ky3) + ky) * dt * 0.125f;
+      adj = adj + (ka1 + 3.f * (ka2 + ka3) + ka) * dt * 0.125f;
+    }
+    adj = adj + upstream(i - 1);
+  }
+
+  // ODEFunc parameter partials
+  {
+    const f32x4 sb1 = sum_over_samples(gb1), sb2 = sum_over_samples(gb2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      part[OFF_W1 + (4 * g + r) * 16 + s] = gW1[r];
+      part[OFF_W2 + (4 * g + r) * 16 + s] = gW2[r];
+    }
+    if (s == 0) {
+      *reinterpret_cast<f32x4*>(part + OFF_B1 + 4 * g) = sb1;
+      *reinterpret_cast<f32x4*>(part + OFF_B2 + 4 * g) = sb2;
+    }
+  }
+
+  // pre-net backward; adj = dL/d(pre-net output)
+  if (a.prenet) {
+    const f32x4 x = valid ? ld4(a.x + n * 16 + 4 * g) : zero4();
+    f32x4 hpre[4];
+    f32x4 acc = ld4(a.p.bb + 4 * g);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      hpre[m] = matvec(ld4(a.p.Wa + (16 * m + s) * 16 + 4 * g), x, ld4(a.p.ba + 16 * m + 4 * g));
+      acc = matvec(ld4(a.p.Wb + s * 64 + 16 * m + 4 * g), lrelu4(hpre[m]), acc);
+    }
+    const f32x4 g0 = lrelu_grad4(acc, adj);
+    const f32x4 sbb = sum_over_samples(g0);
+    if (s == 0) *reinterpret_cast<f32x4*>(part + OFF_BB + 4 * g) = sbb;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 dWb = outer(zero4(), g0, lrelu4(hpre[m]));
+      f32x4 wbt;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        part[OFF_WB + (4 * g + r) * 64 + 16 * m + s] = dWb[r];
+        wbt[r] = a.p.Wb[(4 * g + r) * 64 + 16 * m + s];
+      }
+      const f32x4 gh = lrelu_grad4(hpre[m], matvec(wbt, g0, zero4()));
+      const f32x4 sba = sum_over_samples(gh);
+      if (s == 0) *reinterpret_cast<f32x4*>(part + OFF_BA + 16 * m + 4 * g) = sba;
+      const f32x4 dWa = outer(zero4(), gh, x);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[OFF_WA + (16 * m + 4 * g + r) * 16 + s] = dWa[r];
+    }
+  } else {
+    for (int i = l; i < OFF_W1; i += 64) part[i] = 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(256) ode_bwd_reduce_kernel(const float* work, float* grads, int nblk, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= GODE_ODE_NPARAM) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += work[(int64_t)b * GODE_ODE_NPARAM + i];
+  grads[i] = accumulate ? grads[i] + s : s;
+}
+
+extern "C" int64_t gode_ode_bwd_work_size(int32_t N) { return (int64_t)((N + 15) / 16) * GODE_ODE_NPARAM; }
+
+extern "C" int gode_ode_bwd(const gode_ode_bwd_op* op, void* stream) {
+  if (!op || !op->traj || !op->gz || !op->dt || !op->work || !op->grads || op->N <= 0 || op->T < 1 || op->substeps < 1)
+    return GODE_E_ARG;
+  if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2) return GODE_E_ARG;
+  if (op->prenet && (!op->x || !op->p.Wa || !op->p.ba || !op->p.Wb || !op->p.bb)) return GODE_E_ARG;
+  const int nblk = (op->N + 15) / 16;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ode_bwd_kernel, dim3(nblk), dim3(64), 0, st, *op);
+  GODE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ode_bwd_reduce_kernel, dim3((GODE_ODE_NPARAM + 255) / 256), dim3(256), 0, st, op->work, op->grads,
+                     nblk, op->accumulate);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}

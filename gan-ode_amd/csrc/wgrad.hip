@@ -1,0 +1,261 @@
+// wgrad.hip -- weight gradients of Conv2d/Conv3d/ConvTranspose2d as a split-K fp32-MFMA GEMM.
+//
+//   dW[co][tap][ci] = sum over y positions m of  Y[m][co] * X[pos(m,tap)][ci]
+// (Y = y-side tensor, dense [M][Co]; X = x-side tensor gathered at the tap offset, zero outside).  The reduction
+// index m is the MFMA k index, so both LDS tiles keep the memory order [position][channel] and are read with
+// ds_read_b32 (consecutive lanes -> consecutive channels, conflict free); no transpose is ever materialised.
+// The reduction is cut into `splits` slabs (grid.z), each writing its own [Co][taps*Ci] partial; a second kernel
+// sums the partials in fixed order and scatters into PyTorch's canonical W[co][ci][taps] layout (deterministic,
+// no float atomics).  The BN+activation of the producing layer is fused into whichever operand is an activation.
+#include "common.h"
+#include "conv_geom.h"
+
+struct WgradArgs {
+  gode_conv_geom g;
+  const float* x; const float* y; const float* scale; const float* shift; float* work;
+  int32_t xsN, xsD, xsH, xsW, xsC;
+  int32_t act, xform_on_y;
+  int32_t M, chunk, Kt, taps;
+};
+
+template <int WM, int WN, int TM, int TN, bool VECX, bool VECY>
+__global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgradArgs a) {
+  constexpr int NT = WM * WN * 64, BI = WM * TM * 32, BJ = WN * TN * 32;
+  static_assert(NT == 256, "loader assumes 256 threads");
+  constexpr int YC = BI / 4, XC = BJ / 4;           // float4 chunks per tile row
+  constexpr int YR = NT / YC, XR = NT / XC;         // tile rows per loader pass
+  constexpr int YP = 32 / YR, XP = 32 / XR;         // passes over the 32-position slab
+  static_assert(YP >= 1 && XP >= 1, "tile too narrow for the loader");
+  __shared__ __attribute__((aligned(16))) float smem[2 * 32 * (BI + BJ)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int jblk = blockIdx.x, iblk = blockIdx.y, z = blockIdx.z;
+  const gode_conv_geom& g = a.g;
+  const int m_begin = z * a.chunk;
+  const int m_end = m_begin + a.chunk < a.M ? m_begin + a.chunk : a.M;
+  const int nslab = m_end > m_begin ? (m_end - m_begin + 31) >> 5 : 0;
+
+  // ---- per-thread fixed columns
+  const int ych = tid % YC, yr0 = tid / YC;
+  const int xch = tid % XC, xr0 = tid / XC;
+  const int co0 = iblk * BI + ych * 4;
+  const int j0 = jblk * BJ + xch * 4;
+  int xkd[4], xkh[4], xkw[4], xci[4];
+  bool xok[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = j0 + e;
+    xok[e] = j < a.Kt;
+    const int tap = xok[e] ? j / g.Ci : 0;
+    xci[e] = xok[e] ? j - tap * g.Ci : 0;
+    xkw[e] = tap % g.kw; xkh[e] = (tap / g.kw) % g.kh; xkd[e] = tap / (g.kw * g.kh);
+  }
+  f32x4 xsc = {1, 1, 1, 1}, xsh = {0, 0, 0, 0}, ysc = {1, 1, 1, 1}, ysh = {0, 0, 0, 0};
+  const bool xf = a.scale != nullptr;
+  if (xf) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (!a.xform_on_y && xok[e]) { xsc[e] = a.scale[xci[e]]; xsh[e] = a.shift[xci[e]]; }
+      if (a.xform_on_y && co0 + e < g.Co) { ysc[e] = a.scale[co0 + e]; ysh[e] = a.shift[co0 + e]; }
+    }
+  }
+  const int xact = a.xform_on_y ? GODE_ACT_NONE : a.act, yact = a.xform_on_y ? a.act : GODE_ACT_NONE;
+
+  f32x4 ry[YP], rx[XP];
+
+  auto fetch = [&](int slab) {
+    const int mb = m_begin + slab * 32;
+#pragma unroll
+    for (int p = 0; p < YP; ++p) {
+      const int m = mb + yr0 + p * YR;
+      f32x4 v = {0, 0, 0, 0};
+      if (m < m_end) {
+        if (VECY) {
+          if (co0 < g.Co) v = *reinterpret_cast<const f32x4*>(a.y + (int64_t)m * g.Co + co0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (co0 + e < g.Co) v[e] = a.y[(int64_t)m * g.Co + co0 + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (co0 + e < g.Co) ? gode_act(v[e] * ysc[e] + ysh[e], yact) : 0.f;
+      }
+      ry[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const int m = mb + xr0 + p * XR;
+      f32x4 v = {0, 0, 0, 0};
+      if (m < m_end) {
+        const int qw = m % g.Wo; int t = m / g.Wo;
+        const int qh = t % g.Ho; t /= g.Ho;
+        const int qd = t % g.Do; const int img = t / g.Do;
+        const int bd = qd * g.sd - g.pd, bh = qh * g.sh - g.ph, bw = qw * g.sw - g.pw;
+        const int base = img * a.xsN;
+        if (VECX) {
+          const int id = bd + xkd[0], ih = bh + xkh[0], iw = bw + xkw[0];
+          if (xok[0] && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi) {
+            v = *reinterpret_cast<const f32x4*>(a.x + base + id * a.xsD + ih * a.xsH + iw * a.xsW + xci[0]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gode_act(v[e] * xsc[e] + xsh[e], xact);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int id = bd + xkd[e], ih = bh + xkh[e], iw = bw + xkw[e];
+            if (xok[e] && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi)
+              v[e] = gode_act(a.x[base + id * a.xsD + ih * a.xsH + iw * a.xsW + xci[e] * a.xsC] * xsc[e] + xsh[e], xact);
+          }
+        }
+      }
+      rx[p] = v;
+    }
+  };
+  auto stage = [&](int buf) {
+    float* Ys = smem + buf * 32 * (BI + BJ);
+    float* Xs = Ys + 32 * BI;
+#pragma unroll
+    for (int p = 0; p < YP; ++p) *reinterpret_cast<f32x4*>(Ys + (yr0 + p * YR) * BI + ych * 4) = ry[p];
+#pragma unroll
+    for (int p = 0; p < XP; ++p) *reinterpret_cast<f32x4*>(Xs + (xr0 + p * XR) * BJ + xch * 4) = rx[p];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nslab > 0) {
+    fetch(0);
+    stage(0);
+  }
+  __syncthreads();
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int s = 0; s < nslab; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nslab) fetch(s + 1);
+    const float* Ys = smem + buf * 32 * (BI + BJ) + fh * BI + wm * TM * 32 + fr;
+    const float* Xs = smem + buf * 32 * (BI + BJ) + 32 * BI + fh * BJ + wn * TN * 32 + fr;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = Ys[ks * 2 * BI + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Xs[ks * 2 * BJ + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < nslab) stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* dst = a.work + (int64_t)z * g.Co * a.Kt;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = jblk * BJ + (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = iblk * BI + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < g.Co && col < a.Kt) dst[(int64_t)row * a.Kt + col] = acc[i][j][r];
+      }
+    }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* work, float* dw, int Co, int Ci, int taps,
+                                                           int splits, const int32_t* co_perm, int accumulate) {
+  const int Kt = Ci * taps;
+  const int64_t total = (int64_t)Co * Kt;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int zz = 0; zz < splits; ++zz) s += work[(int64_t)zz * total + i];
+    int co = (int)(i / Kt);
+    const int j = (int)(i - (int64_t)co * Kt);
+    const int tap = j / Ci, ci = j - tap * Ci;
+    if (co_perm) { co = co_perm[co]; if (co < 0) continue; }
+    float* d = dw + ((int64_t)co * Ci + ci) * taps + tap;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static int wg_tile(const gode_conv_geom& g) { return g.Co <= 32 ? 0 : (g.Co <= 64 ? 1 : 2); }
+static int wg_bi(int t) { return t == 0 ? 32 : (t == 1 ? 64 : 128); }
+
+extern "C" int gode_wgrad_auto_splits(const gode_conv_geom* g) {
+  const int taps = g->kd * g->kh * g->kw, Kt = taps * g->Ci;
+  const int64_t M = (int64_t)g->N * g->Do * g->Ho * g->Wo;
+  const int64_t tiles = (int64_t)gode_ceil_div(g->Co, wg_bi(wg_tile(*g))) * gode_ceil_div(Kt, 128);
+  int64_t s = (768 + tiles - 1) / tiles;
+  const int64_t cap = (M + 63) / 64;
+  if (s > cap) s = cap;
+  if (s > 256) s = 256;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+static int wg_splits(const gode_wgrad_op* op) { return op->splits > 0 ? op->splits : gode_wgrad_auto_splits(&op->g); }
+
+extern "C" int64_t gode_wgrad_work_size(const gode_wgrad_op* op) {
+  const int taps = op->g.kd * op->g.kh * op->g.kw;
+  return (int64_t)wg_splits(op) * op->g.Co * taps * op->g.Ci;
+}
+
+template <int WM, int WN, int TM, int TN>
+static int wg_launch(const WgradArgs& A, bool vx, bool vy, int splits, hipStream_t st) {
+  constexpr int BI = WM * TM * 32, BJ = WN * TN * 32;
+  dim3 grid(gode_ceil_div(A.Kt, BJ), gode_ceil_div(A.g.Co, BI), splits), block(256);
+  if (vx && vy) hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, true, true>), grid, block, 0, st, A);
+  else if (vx) hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, true, false>), grid, block, 0, st, A);
+  else if (vy) hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, false, true>), grid, block, 0, st, A);
+  else hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, false, false>), grid, block, 0, st, A);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gode_wgrad(const gode_wgrad_op* op, void* stream) {
+  if (!op || !op->x || !op->y || !op->work || !op->dw) return GODE_E_ARG;
+  const gode_conv_geom& g = op->g;
+  IgemmGeom chk;
+  int rc = gode_build_igemm_geom(g, GODE_FPROP, &chk);  // validates the conv relation
+  if (rc) return rc;
+  WgradArgs A;
+  A.g = g; A.x = op->x; A.y = op->y; A.scale = op->scale; A.shift = op->shift; A.work = op->work;
+  int64_t xs[5];
+  if (gode_strides_are_channels_last(op->xs)) {
+    xs[4] = 1; xs[3] = g.Ci; xs[2] = (int64_t)g.Wi * xs[3]; xs[1] = (int64_t)g.Hi * xs[2]; xs[0] = (int64_t)g.Di * xs[1];
+  } else {
+    for (int i = 0; i < 5; ++i) xs[i] = op->xs[i];
+  }
+  int64_t span = 1 + (int64_t)(g.N - 1) * xs[0] + (int64_t)(g.Di - 1) * xs[1] + (int64_t)(g.Hi - 1) * xs[2] +
+                 (int64_t)(g.Wi - 1) * xs[3] + (int64_t)(g.Ci - 1) * xs[4];
+  const int64_t M = (int64_t)g.N * g.Do * g.Ho * g.Wo;
+  if (span >= (1ll << 31) || M * g.Co >= (1ll << 31)) return GODE_E_SHAPE;
+  A.xsN = (int)xs[0]; A.xsD = (int)xs[1]; A.xsH = (int)xs[2]; A.xsW = (int)xs[3]; A.xsC = (int)xs[4];
+  A.act = op->act; A.xform_on_y = op->xform_on_y;
+  A.M = (int)M; A.taps = g.kd * g.kh * g.kw; A.Kt = A.taps * g.Ci;
+  const int splits = wg_splits(op);
+  A.chunk = (int)(((M + splits - 1) / splits + 31) / 32 * 32);
+  const bool vx = xs[4] == 1 && g.Ci % 4 == 0 && xs[0] % 4 == 0 && xs[1] % 4 == 0 && xs[2] % 4 == 0 && xs[3] % 4 == 0 &&
+                  (uintptr_t)op->x % 16 == 0;
+  const bool vy = g.Co % 4 == 0 && (uintptr_t)op->y % 16 == 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int t = wg_tile(g);
+  if (t == 0) rc = wg_launch<1, 4, 1, 1>(A, vx, vy, splits, st);
+  else if (t == 1) rc = wg_launch<2, 2, 1, 2>(A, vx, vy, splits, st);
+  else rc = wg_launch<2, 2, 2, 2>(A, vx, vy, splits, st);
+  if (rc) return rc;
+  const int64_t total = (int64_t)g.Co * A.Kt;
+  int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, op->work, op->dw, g.Co, g.Ci, A.taps, splits,
+                     op->co_perm, op->accumulate);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,325 @@
+"""Host-side plans: turn one network pass (generator decoder, video/image discriminator) into a fixed list of
+libgode ops over pre-allocated device buffers, executed by a single gode_run call.
+
+A ConvStack is a chain of  conv -> [train-mode BatchNorm] -> activation  layers.  Every layer stores only its RAW
+(pre-BatchNorm) output, channels-last; BatchNorm + activation are applied by the consumer kernel while it loads its
+operand, so each activation tensor crosses HBM once per use.  Layers are described in conv orientation
+(gode_conv_geom); a ConvTranspose2d layer is the DGRAD of its geometry, so the generator decoder
+(models/mocogan.py:200-215, models/mocogan_ode.py:66-84) and the discriminators (models/mocogan.py:72-89,138-159)
+share all kernels and this class.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+
+def make_geom(N, Ci, Co, xi, yo, k, s, p) -> L.ConvGeom:
+    """xi / yo / k / s / p are (d, h, w) triples in conv orientation."""
+    return L.ConvGeom(N, Ci, Co, xi[0], xi[1], xi[2], yo[0], yo[1], yo[2], k[0], k[1], k[2], s[0], s[1], s[2],
+                      p[0], p[1], p[2])
+
+
+def conv_out(i, k, s, p):
+    return (i + 2 * p - k) // s + 1
+
+
+def dptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@dataclass
+class LayerSpec:
+    geom: L.ConvGeom
+    fwd_dir: int                 # L.FPROP (Conv) or L.DGRAD (ConvTranspose)
+    act: int                     # activation applied to this layer's output (by the consumer)
+    has_bn: bool
+    epilogue: int = L.EPI_RAW    # only the last layer: tanh
+    co_perm: Optional[torch.Tensor] = None  # int32 device tensor (generator layer 0)
+
+    def out_dims(self):
+        g = self.geom
+        if self.fwd_dir == L.FPROP:
+            return (g.N, g.Do, g.Ho, g.Wo, g.Co)
+        return (g.N, g.Di, g.Hi, g.Wi, g.Ci)
+
+    def in_dims(self):
+        g = self.geom
+        if self.fwd_dir == L.FPROP:
+            return (g.N, g.Di, g.Hi, g.Wi, g.Ci)
+        return (g.N, g.Do, g.Ho, g.Wo, g.Co)
+
+
+@dataclass
+class LayerParams:
+    weight: torch.Tensor
+    gamma: Optional[torch.Tensor] = None
+    beta: Optional[torch.Tensor] = None
+    running_mean: Optional[torch.Tensor] = None
+    running_var: Optional[torch.Tensor] = None
+    num_batches_tracked: Optional[torch.Tensor] = None
+
+
+def _contig_strides(dims):
+    """channels-last element strides {N,D,H,W,C} of a contiguous [N,D,H,W,C] buffer."""
+    n, d, h, w, c = dims
+    return (d * h * w * c, h * w * c, w * c, c, 1)
+
+
+class ConvStack:
+    """Forward/backward programs of one conv stack at a fixed batch size.
+
+    input: either a plan-owned channels-last buffer (`self.x_in`, generator latent rows) or a caller tensor given
+    per call with element strides (discriminators read the caller's video / image in place)."""
+
+    def __init__(self, specs: Sequence[LayerSpec], params: Sequence[LayerParams], device, owns_input: bool,
+                 momentum=0.1, eps=1e-5):
+        self.specs, self.params, self.device = list(specs), list(params), device
+        self.nl = len(specs)
+        self.momentum, self.eps = momentum, eps
+        self.busy = False
+        lib = L.lib()
+        f32 = dict(dtype=torch.float32, device=device)
+        self.x_in = torch.zeros(specs[0].in_dims(), **f32) if owns_input else None
+        # raw outputs of all but the last layer are plan-owned; the last is allocated per call
+        self.y = [torch.empty(s.out_dims(), **f32) for s in specs[:-1]]
+        self.out_dims = specs[-1].out_dims()
+        self.wpack_f, self.wpack_b = [], [None] * self.nl
+        self.stats, self.stat_rows = [], []
+        self.mean, self.invstd, self.scale, self.shift = [], [], [], []
+        for s in specs:
+            n = lib.gode_pack_size(C.byref(s.geom), s.fwd_dir)
+            if n <= 0:
+                raise RuntimeError(f"bad geometry for pack ({n})")
+            self.wpack_f.append(torch.empty(n, **f32))
+            C_out = s.out_dims()[4]
+            if s.has_bn:
+                probe = L.IgemmOp(g=s.geom, dir=s.fwd_dir, tile=0)
+                rows = lib.gode_igemm_stats_rows(C.byref(probe))
+                ncols = self._ncols(s)
+                self.stat_rows.append(rows)
+                self.stats.append(torch.empty(rows * 2 * ncols, **f32))
+                self.mean.append(torch.empty(C_out, **f32)); self.invstd.append(torch.empty(C_out, **f32))
+                self.scale.append(torch.empty(C_out, **f32)); self.shift.append(torch.empty(C_out, **f32))
+            else:
+                self.stat_rows.append(0); self.stats.append(None)
+                self.mean.append(None); self.invstd.append(None); self.scale.append(None); self.shift.append(None)
+        self._fwd = {}          # training flag -> Program
+        self._bwd = None
+        self._bwd_need_input = None
+        self.g = None           # gradient buffers (lazy)
+        self._param_ptrs = None
+
+    # -- helpers -------------------------------------------------------------------------------------------
+    @staticmethod
+    def _ncols(s: LayerSpec):
+        g = s.geom
+        if s.fwd_dir == L.FPROP:
+            return g.Co
+        fullk = (g.Do == 1 and g.Ho == 1 and g.Wo == 1 and g.pd == 0 and g.ph == 0 and g.pw == 0 and
+                 g.Di == g.kd and g.Hi == g.kh and g.Wi == g.kw and g.kd * g.kh * g.kw > 1)
+        return g.kd * g.kh * g.kw * g.Ci if fullk else g.Ci
+
+    def _in_xform(self, l):
+        """(scale, shift, act) the consumer of layer l-1's raw output applies."""
+        if l == 0:
+            return None, None, L.ACT_NONE
+        s = self.specs[l - 1]
+        return (self.scale[l - 1], self.shift[l - 1], s.act) if s.has_bn else (None, None, s.act)
+
+    def _count(self, l):
+        d = self.specs[l].out_dims()
+        return d[0] * d[1] * d[2] * d[3]
+
+    def param_ptrs(self):
+        out = []
+        for p in self.params:
+            for t in (p.weight, p.gamma, p.beta, p.running_mean, p.running_var, p.num_batches_tracked):
+                out.append(None if t is None else t.data_ptr())
+        return tuple(out)
+
+    def _refresh(self):
+        """Programs hold raw parameter pointers; rebuild them if a module was moved/re-allocated."""
+        ptrs = self.param_ptrs()
+        if ptrs != self._param_ptrs:
+            self._fwd, self._bwd, self._param_ptrs = {}, None, ptrs
+
+    # -- forward -------------------------------------------------------------------------------------------
+    def _build_fwd(self, training: bool):
+        ops = []
+        patch = {}
+        for l, (s, p) in enumerate(zip(self.specs, self.params)):
+            ops.append(L.PackOp(g=s.geom, dir=s.fwd_dir, co_canon=0, w=dptr(p.weight), wpack=dptr(self.wpack_f[l]),
+                                co_perm=dptr(s.co_perm)))
+            sc, sh, act = self._in_xform(l)
+            src = self.x_in if l == 0 else self.y[l - 1]
+            op = L.IgemmOp(g=s.geom, dir=s.fwd_dir, act=act, epilogue=s.epilogue, tile=0, src=dptr(src),
+                           wpack=dptr(self.wpack_f[l]), out=dptr(self.y[l]) if l < self.nl - 1 else None,
+                           scale=dptr(sc), shift=dptr(sh),
+                           stats=dptr(self.stats[l]) if (s.has_bn and training) else None)
+            ops.append(op)
+            if l == 0:
+                patch["first"] = op
+            if l == self.nl - 1:
+                patch["last"] = op
+            if s.has_bn:
+                ops.append(L.BnFinalizeOp(stats=dptr(self.stats[l]), rows=self.stat_rows[l], ncols=self._ncols(s),
+                                          C=s.out_dims()[4], count=self._count(l), gamma=dptr(p.gamma),
+                                          beta=dptr(p.beta), running_mean=dptr(p.running_mean),
+                                          running_var=dptr(p.running_var),
+                                          num_batches_tracked=dptr(p.num_batches_tracked), mean=dptr(self.mean[l]),
+                                          invstd=dptr(self.invstd[l]), scale=dptr(self.scale[l]),
+                                          shift=dptr(self.shift[l]), momentum=self.momentum, eps=self.eps,
+                                          training=1 if training else 0))
+        return L.Program(ops), patch
+
+    def forward(self, training: bool, x: Optional[torch.Tensor] = None, x_strides=None, pre_ops_program=None):
+        """Runs the stack.  x (+ element strides {N,D,H,W,C}) is required when the plan does not own its input.
+        Returns the freshly allocated last-layer output [N,D,H,W,C]."""
+        self._refresh()
+        if training not in self._fwd:
+            self._fwd[training] = self._build_fwd(training)
+        prog, patch = self._fwd[training]
+        out = torch.empty(self.out_dims, dtype=torch.float32, device=self.device)
+        patch["last"].out = out.data_ptr()
+        if self.x_in is None:
+            first = patch["first"]
+            first.src = x.data_ptr()
+            for i in range(5):
+                first.gs[i] = int(x_strides[i])
+            self._x_user, self._x_strides = x, tuple(int(v) for v in x_strides)
+        st = stream_ptr()
+        if pre_ops_program is not None:
+            pre_ops_program.run(st)
+        prog.run(st)
+        self.out = out
+        return out
+
+    # -- backward ------------------------------------------------------------------------------------------
+    def n_grad_floats(self):
+        n = 0
+        for p in self.params:
+            n += p.weight.numel()
+            if p.gamma is not None:
+                n += p.gamma.numel() + p.beta.numel()
+        return n
+
+    def _build_bwd(self, need_input_grad: bool, need_param_grad: bool = True):
+        lib = L.lib()
+        f32 = dict(dtype=torch.float32, device=self.device)
+        if self.g is None:
+            self.g = [torch.empty(s.out_dims(), **f32) for s in self.specs]  # grad wrt raw/activated outputs
+            self.g_in = torch.empty(self.specs[0].in_dims(), **f32)
+        ops, patch = [], {"dw": [], "dgamma": [], "dbeta": []}
+        wg_work = 0
+        bn_work = 0
+        last = self.specs[-1]
+        if last.epilogue == L.EPI_TANH:
+            M = self._count(self.nl - 1)
+            op = L.BnBwdOp(g=dptr(self.g[-1]), y=None, M=M, C=last.out_dims()[4], act=L.ACT_TANH_OUT)
+            patch["tanh"] = op
+            ops.append(op)
+        for l in range(self.nl - 1, -1, -1):
+            s, p = self.specs[l], self.params[l]
+            rev = L.DGRAD if s.fwd_dir == L.FPROP else L.FPROP
+            sc, sh, act = self._in_xform(l)
+            src = self.x_in if l == 0 else self.y[l - 1]
+            # weight gradient
+            if s.fwd_dir == L.FPROP:
+                w = L.WgradOp(g=s.geom, act=act, xform_on_y=0, splits=0, accumulate=0, x=dptr(src), y=dptr(self.g[l]),
+                              scale=dptr(sc), shift=dptr(sh), co_perm=dptr(s.co_perm))
+            else:
+                w = L.WgradOp(g=s.geom, act=act, xform_on_y=1, splits=0, accumulate=0, x=dptr(self.g[l]), y=dptr(src),
+                              scale=dptr(sc), shift=dptr(sh), co_perm=dptr(s.co_perm))
+            if need_param_grad:
+                wg_work = max(wg_work, lib.gode_wgrad_work_size(C.byref(w)))
+                patch["dw"].append((l, w))
+                if l == 0:
+                    patch["wgrad0"] = w
+                ops.append(w)
+            # input gradient
+            if l > 0 or need_input_grad:
+                if self.wpack_b[l] is None:
+                    self.wpack_b[l] = torch.empty(lib.gode_pack_size(C.byref(s.geom), rev), **f32)
+                ops.append(L.PackOp(g=s.geom, dir=rev, co_canon=0, w=dptr(p.weight), wpack=dptr(self.wpack_b[l]),
+                                    co_perm=dptr(s.co_perm)))
+                dst = self.g_in if l == 0 else self.g[l - 1]
+                ops.append(L.IgemmOp(g=s.geom, dir=rev, act=L.ACT_NONE, epilogue=L.EPI_RAW, tile=0, src=dptr(self.g[l]),
+                                     wpack=dptr(self.wpack_b[l]), out=dptr(dst)))
+            if l > 0:
+                sp, pp = self.specs[l - 1], self.params[l - 1]
+                M, Cc = self._count(l - 1), sp.out_dims()[4]
+                if sp.has_bn:
+                    b = L.BnBwdOp(g=dptr(self.g[l - 1]), y=dptr(self.y[l - 1]), M=M, C=Cc, act=sp.act,
+                                  gamma=dptr(pp.gamma), mean=dptr(self.mean[l - 1]), invstd=dptr(self.invstd[l - 1]),
+                                  scale=dptr(self.scale[l - 1]), shift=dptr(self.shift[l - 1]), accumulate=0)
+                    bn_work = max(bn_work, lib.gode_bn_bwd_work_size(M, Cc))
+                    if need_param_grad:
+                        patch["dgamma"].append((l - 1, b))
+                else:
+                    b = L.BnBwdOp(g=dptr(self.g[l - 1]), y=dptr(self.y[l - 1]), M=M, C=Cc, act=sp.act)
+                patch.setdefault("bnb", []).append(b)
+                ops.append(b)
+        self.wg_work = torch.empty(max(wg_work, 1), **f32)
+        self.bn_work = torch.empty(max(bn_work, 1), **f32)
+        for _, w in patch["dw"]:
+            w.work = self.wg_work.data_ptr()
+        for b in patch.get("bnb", []):
+            if b.mean:
+                b.work = self.bn_work.data_ptr()
+        return L.Program(ops), patch
+
+    def backward(self, gout: torch.Tensor, need_input_grad: bool, need_param_grad: bool = True):
+        """gout: gradient wrt the (activated) output, any strides, logical dims = self.out_dims.
+        Returns (flat parameter gradients or None, per-layer views list, input gradient buffer or None)."""
+        self._refresh()
+        key = (need_input_grad, need_param_grad)
+        if self._bwd is None or self._bwd_need_input != key:
+            self._bwd = self._build_bwd(need_input_grad, need_param_grad)
+            self._bwd_need_input = key
+        prog, patch = self._bwd
+        self.g[-1].copy_(gout)
+        if "tanh" in patch:
+            patch["tanh"].y = self.out.data_ptr()
+        flat = torch.empty(self.n_grad_floats() if need_param_grad else 1, dtype=torch.float32, device=self.device)
+        views, off = [], 0
+        if not need_param_grad:
+            prog.run(stream_ptr())
+            self.busy = False
+            return None, None, (self.g_in if need_input_grad else None)
+        per_layer = {}
+        for l, p in enumerate(self.params):
+            n = p.weight.numel()
+            wv = flat[off:off + n].view_as(p.weight); off += n
+            gv = bv = None
+            if p.gamma is not None:
+                c = p.gamma.numel()
+                gv = flat[off:off + c]; off += c
+                bv = flat[off:off + c]; off += c
+            per_layer[l] = (wv, gv, bv)
+            views.append((wv, gv, bv))
+        for l, w in patch["dw"]:
+            w.dw = per_layer[l][0].data_ptr()
+        for l, b in patch["dgamma"]:
+            b.dgamma = per_layer[l][1].data_ptr()
+            b.dbeta = per_layer[l][2].data_ptr()
+        if self.x_in is None and "wgrad0" in patch:
+            w0 = patch["wgrad0"]
+            tgt = "x" if self.specs[0].fwd_dir == L.FPROP else "y"
+            if tgt != "x":
+                raise RuntimeError("caller-owned input is only supported for Conv (FPROP) stacks")
+            w0.x = self._x_user.data_ptr()
+            for i in range(5):
+                w0.xs[i] = self._x_strides[i]
+        prog.run(stream_ptr())
+        self.busy = False
+        return flat, views, (self.g_in if need_input_grad else None)

@@ -1,0 +1,502 @@
+"""nn.Module surface of the hot path, mirroring the reference's classes (same names, constructor signatures,
+state_dict keys, RNG consumption and return conventions) with all device arithmetic lowered to libgode.so.
+
+Reference: models/mocogan.py (Noise :20-29, PatchImageDiscriminator :66-93, VideoDiscriminator :129-164,
+VideoGenerator :185-301) and models/mocogan_ode.py (ODEFunc :6-17, VideoGenerator :20-54, VideoGeneratorMNIST
+:57-111, VideoGeneratorMNISTODE :114-148).
+
+The child modules under ``main`` / ``ode_fn`` / ``linear`` / ``recurrent`` are stock torch.nn layers used ONLY as
+parameter containers (default init, state_dict keys, .cuda()/.to()); they are never called.  Every forward goes
+through the HIP kernels and raises if the tensors are not on the GPU or libgode.so is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .engine import ConvStack, LayerParams, LayerSpec, conv_out, dptr, make_geom, stream_ptr
+
+Z_COLS = 72  # latent row: [motion 16 | content 50 | zero pad 6]
+
+
+def _require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: this implementation runs only on an MI355X through libgode.so; move the module "
+                           "to the GPU with .cuda() (there is no CPU or PyTorch fallback)")
+
+
+class _Pool:
+    """Plans own their activation buffers; a plan stays checked out between a forward that saved state for autograd
+    and its backward, so two overlapping passes of the same shape (D(real), D(fake)) get distinct plans."""
+
+    def __init__(self):
+        self.plans = {}
+
+    def get(self, key, factory):
+        lst = self.plans.setdefault(key, [])
+        for p in lst:
+            if not p.busy:
+                return p
+        if len(lst) >= 6:          # forwards whose backward never came (loss dropped): recycle the oldest plan
+            p = lst.pop(0)
+            p.busy = False
+            lst.append(p)
+            return p
+        p = factory()
+        lst.append(p)
+        return p
+
+    def clear(self):
+        self.plans.clear()
+
+
+# ==================================================================================================================
+# generator
+# ==================================================================================================================
+class ODEFunc(nn.Module):
+    """Right-hand side f(t, x) = W2 tanh(W1 x + b1) + b2 (models/mocogan_ode.py:6-17).  Evaluated inside the fused
+    ODE kernels; calling it directly is not part of the hot path."""
+
+    def __init__(self, dim, dim_hidden):
+        super().__init__()
+        self.fn = nn.Sequential(nn.Linear(dim, dim_hidden), nn.Tanh(), nn.Linear(dim_hidden, dim))
+
+    def forward(self, t, x):
+        raise RuntimeError("ODEFunc is evaluated inside libgode's fused RK4 kernels (gode_ode_fwd/bwd)")
+
+
+class _GenPlan:
+    """ODE solve + decoder for `n_traj` trajectories.  full: rows = n_traj*T; select: rows = n_traj (one chosen
+    time per trajectory, sample_images)."""
+
+    def __init__(self, gen: "VideoGenerator", n_traj: int, T: int, select: bool):
+        dev = gen.main[0].weight.device
+        self.gen, self.n, self.T, self.select, self.device = gen, n_traj, T, select, dev
+        self.rows = n_traj if select else n_traj * T
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.x = torch.empty(n_traj, 16, **f32)
+        self.content = torch.empty(n_traj, 50, **f32)
+        self.traj = torch.empty(n_traj, T, 16, **f32)
+        self.sel = torch.zeros(n_traj, dtype=torch.int32, device=dev) if select else None
+        tt = torch.linspace(0, 1, T).float()            # models/mocogan_ode.py:143 -- fp32 grid built on the host
+        self.dt = (tt[1:] - tt[:-1]).to(dev) if T > 1 else torch.zeros(1, **f32)
+        self.stack = ConvStack(gen._decoder_specs(self.rows), gen._decoder_params(), dev, owns_input=True)
+        self.ode_work = torch.empty(L.lib().gode_ode_bwd_work_size(n_traj), **f32)
+        self._ode_ptrs = None
+        self.busy = False
+
+    def _ode_params(self):
+        g = self.gen
+        lin = g.linear
+        if isinstance(lin, nn.Identity):
+            pre = (None, None, None, None)
+        else:
+            pre = (lin[0].weight, lin[0].bias, lin[2].weight, lin[2].bias)
+        f = g.ode_fn.fn
+        return pre + (f[0].weight, f[0].bias, f[2].weight, f[2].bias)
+
+    def _programs(self):
+        ps = self._ode_params()
+        ptrs = tuple(dptr(p) for p in ps)
+        if ptrs != self._ode_ptrs:
+            self._ode_ptrs = ptrs
+            op = L.OdeParams(*ptrs)
+            prenet = 0 if ps[0] is None else 1
+            self.fwd_op = L.OdeFwdOp(p=op, x=dptr(self.x), content=dptr(self.content), dt=dptr(self.dt),
+                                     sel_t=dptr(self.sel), z=dptr(self.stack.x_in), traj=dptr(self.traj), N=self.n,
+                                     T=self.T, substeps=self.gen.ode_substeps, prenet=prenet)
+            self.bwd_op = L.OdeBwdOp(p=op, x=dptr(self.x), traj=dptr(self.traj), dt=dptr(self.dt),
+                                     sel_t=dptr(self.sel), gz=None, work=dptr(self.ode_work), grads=None, N=self.n,
+                                     T=self.T, substeps=self.gen.ode_substeps, prenet=prenet, accumulate=0)
+            self.fwd_prog = L.Program([self.fwd_op])
+        self.fwd_op.substeps = self.bwd_op.substeps = self.gen.ode_substeps
+
+    def forward(self, x_host, content_host, sel_host, training, keep):
+        self._programs()
+        self.x.copy_(x_host, non_blocking=True)
+        self.content.copy_(content_host, non_blocking=True)
+        if self.select:
+            self.sel.copy_(sel_host, non_blocking=True)
+        out = self.stack.forward(training, pre_ops_program=self.fwd_prog)
+        self.busy = keep
+        return out
+
+    def backward(self, gout):
+        flat, views, gz = self.stack.backward(gout, need_input_grad=True)
+        grads = torch.empty(L.ODE_NPARAM, dtype=torch.float32, device=self.device)
+        self.bwd_op.gz = gz.data_ptr()
+        self.bwd_op.grads = grads.data_ptr()
+        L.run_one(self.bwd_op, stream_ptr())
+        self.busy = False
+        return views, grads
+
+
+class _GenFn(torch.autograd.Function):
+    """Whole generator pass (pre-net + RK4 + decoder) as one autograd node; backward = decoder backward + adjoint."""
+
+    @staticmethod
+    def forward(ctx, plan, x_host, content_host, sel_host, training, keep, n_dec, *params):
+        out = plan.forward(x_host, content_host, sel_host, training, keep)
+        ctx.plan, ctx.n_dec, ctx.n_params = plan, n_dec, len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        plan = ctx.plan
+        views, og = plan.backward(gout)
+        grads = []
+        for wv, gv, bv in views:
+            grads.append(wv)
+            if gv is not None:
+                grads += [gv, bv]
+        assert len(grads) == ctx.n_dec
+        offs = [(0, 1024, (64, 16)), (1024, 64, (64,)), (1088, 1024, (16, 64)), (2112, 16, (16,)),
+                (2128, 256, (16, 16)), (2384, 16, (16,)), (2400, 256, (16, 16)), (2656, 16, (16,))]
+        n_ode = ctx.n_params - ctx.n_dec
+        for o, n, shp in (offs if n_ode == 8 else offs[4:]):
+            grads.append(og[o:o + n].view(shp))
+        return (None, None, None, None, None, None, None, *grads)
+
+
+class VideoGenerator(nn.Module):
+    """MoCoGAN generator whose motion latent is a Neural ODE (models/mocogan_ode.py:20-54), 64x64 decoder
+    (models/mocogan.py:200-215).  `ode_substeps` (build extension, default 1 = the reference's one RK4 step per
+    output interval) sub-divides each interval."""
+
+    mnist = False
+
+    def __init__(self, n_channels, dim_z_content, dim_z_category, dim_z_motion, video_length, ode_fn=ODEFunc,
+                 dim_hidden=None, linear=True, ngf=64):
+        super().__init__()
+        if dim_z_category != 0:
+            raise NotImplementedError("categorical latents are never used by the stage-3 scripts (dim_z_category=0)")
+        if dim_z_motion != 16 or dim_z_content != 50:
+            raise NotImplementedError("libgode's fused ODE kernels are specialised for dim_z_motion=16, "
+                                      "dim_z_content=50 (mnist_moco_ode.py:78, ucf_moco_ode.py:80)")
+        self.n_channels, self.dim_z_content, self.dim_z_category = n_channels, dim_z_content, dim_z_category
+        self.dim_z_motion, self.video_length, self.ngf = dim_z_motion, video_length, ngf
+        self.ode_substeps = 1
+        dim_z = dim_z_motion + dim_z_category + dim_z_content
+        # construction order == the reference's, so that a given torch seed yields the same initial weights
+        self.recurrent = nn.GRUCell(dim_z_motion, dim_z_motion)       # models/mocogan.py:198 (unused by ODE path)
+        self.main = self._make_main(dim_z, ngf, n_channels, mnist=False)  # base class always builds the 64x64 stack
+        self._init_ode_parts(ode_fn, dim_hidden, linear, dim_z, ngf)
+        self._pool = _Pool()
+
+    def _init_ode_parts(self, ode_fn, dim_hidden, linear, dim_z, ngf):
+        if dim_hidden is None:
+            # the reference passes no dim_hidden here and its ODEFunc then raises TypeError;
+            # keep the failure mode but say why.
+            raise TypeError("ODEFunc.__init__() missing 1 required positional argument: 'dim_hidden' "
+                            "(pass dim_hidden=16; ucf_moco_ode.py:80 omits it and fails the same way)")
+        self.ode_fn = ode_fn(dim=self.dim_z_motion, dim_hidden=dim_hidden)
+        self.linear = self._make_prenet(linear)
+
+    def _make_prenet(self, linear):
+        if not linear:
+            return nn.Identity()
+        d = self.dim_z_motion
+        return nn.Sequential(nn.Linear(d, 64), nn.LeakyReLU(0.2), nn.Linear(64, d), nn.LeakyReLU(0.2))
+
+    @staticmethod
+    def _make_main(dim_z, ngf, n_channels, mnist):
+        w = [dim_z, ngf * 8, ngf * 4, ngf * 2, ngf]
+        layers = []
+        for i in range(4):
+            st, pd = (1, 0) if i == 0 else (2, 1)
+            layers += [nn.ConvTranspose2d(w[i], w[i + 1], 4, st, pd, bias=False), nn.BatchNorm2d(w[i + 1]), nn.ReLU(True)]
+        if mnist:
+            layers.append(nn.ConvTranspose2d(ngf, n_channels, kernel_size=1, stride=1, padding=2, bias=False))
+        else:
+            layers.append(nn.ConvTranspose2d(ngf, n_channels, 4, 2, 1, bias=False))
+        layers.append(nn.Tanh())
+        return nn.Sequential(*layers)
+
+    # -- plan description ----------------------------------------------------------------------------------------
+    def _decoder_specs(self, rows):
+        ngf, nc = self.ngf, self.n_channels
+        dev = self.main[0].weight.device
+        perm = torch.tensor([50 + i for i in range(16)] + list(range(50)) + [-1] * 6, dtype=torch.int32, device=dev)
+        one = (1, 1, 1)
+        specs = [LayerSpec(make_geom(rows, ngf * 8, Z_COLS, (1, 4, 4), one, (1, 4, 4), one, (0, 0, 0)), L.DGRAD,
+                           L.ACT_RELU, True, co_perm=perm)]
+        hw = 4
+        for ci, co in ((ngf * 4, ngf * 8), (ngf * 2, ngf * 4), (ngf, ngf * 2)):
+            specs.append(LayerSpec(make_geom(rows, ci, co, (1, hw * 2, hw * 2), (1, hw, hw), (1, 4, 4), (1, 2, 2),
+                                             (0, 1, 1)), L.DGRAD, L.ACT_RELU, True))
+            hw *= 2
+        if self.mnist:   # ConvTranspose2d(ngf, C, 1, 1, padding=2): a 1x1 conv on the centre 28x28 crop
+            specs.append(LayerSpec(make_geom(rows, nc, ngf, (1, 28, 28), (1, 32, 32), one, one, (0, 2, 2)), L.DGRAD,
+                                   L.ACT_NONE, False, epilogue=L.EPI_TANH))
+        else:
+            specs.append(LayerSpec(make_geom(rows, nc, ngf, (1, 64, 64), (1, 32, 32), (1, 4, 4), (1, 2, 2), (0, 1, 1)),
+                                   L.DGRAD, L.ACT_NONE, False, epilogue=L.EPI_TANH))
+        return specs
+
+    def _decoder_params(self):
+        m = self.main
+        out = []
+        for i in range(4):
+            conv, bn = m[3 * i], m[3 * i + 1]
+            out.append(LayerParams(conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                   bn.num_batches_tracked))
+        out.append(LayerParams(m[12].weight))
+        return out
+
+    def _param_list(self):
+        dec = []
+        for p in self._decoder_params():
+            dec.append(p.weight)
+            if p.gamma is not None:
+                dec += [p.gamma, p.beta]
+        ode = []
+        if not isinstance(self.linear, nn.Identity):
+            ode += [self.linear[0].weight, self.linear[0].bias, self.linear[2].weight, self.linear[2].bias]
+        f = self.ode_fn.fn
+        ode += [f[0].weight, f[0].bias, f[2].weight, f[2].bias]
+        return dec, ode
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        if hasattr(self, "_pool"):
+            self._pool.clear()   # parameter storage may have moved
+        return r
+
+    # -- host-side latent draws: RNG call order is part of the contract ---------------------------------------
+    def _draw(self, num_samples, video_len):
+        """NumPy normal for the content code first (models/mocogan.py:252), then torch.randn on the CPU generator
+        for the ODE's initial noise (models/mocogan_ode.py:136)."""
+        content = np.random.normal(0, 1, (num_samples, self.dim_z_content)).astype(np.float32)
+        x = torch.randn(num_samples, self.dim_z_motion)
+        return torch.from_numpy(content), x
+
+    def _run(self, n_traj, T, select, x, content, sel):
+        _require_gpu(self.main[0].weight, type(self).__name__)
+        plan = self._pool.get((n_traj, T, select), lambda: _GenPlan(self, n_traj, T, select))
+        dec, ode = self._param_list()
+        # (grad mode is off inside Function.forward, so decide here whether the plan must be kept for a backward)
+        keep = torch.is_grad_enabled() and any(p.requires_grad for p in dec + ode)
+        return _GenFn.apply(plan, x, content, sel, self.training, keep, len(dec), *dec, *ode)
+
+    # -- reference API ---------------------------------------------------------------------------------------------
+    def sample_videos(self, num_samples, video_len=None):
+        """-> (videos [B, C, T, H, W] fp32, float64 zero labels [B]); models/mocogan.py:271-285."""
+        T = video_len if video_len is not None else self.video_length
+        content, x = self._draw(num_samples, T)
+        h = self._run(num_samples, T, False, x, content, None)            # [B*T, 1, H, W, C]
+        H, W = h.size(2), h.size(3)
+        h = h.view(num_samples, T, H, W, self.n_channels).permute(0, 4, 1, 2, 3)
+        labels = torch.from_numpy(np.zeros(num_samples)).to(h.device)
+        return h, labels
+
+    def sample_images(self, num_samples):
+        """-> (images [B, C, H, W], None); models/mocogan.py:287-295.  The reference integrates B*T*2 trajectories
+        and decodes B randomly chosen rows of the B*T*2*T latent rows; the draws are reproduced exactly on the host
+        and only the chosen trajectories are integrated (exact: trajectories are independent and unselected rows
+        receive no gradient)."""
+        T = self.video_length
+        n_all = num_samples * T * 2
+        content, x = self._draw(n_all, T)
+        j = np.sort(np.random.choice(n_all * T, num_samples, replace=False)).astype(np.int64)
+        traj = torch.from_numpy(j // T)
+        sel = torch.from_numpy((j % T).astype(np.int32))
+        h = self._run(num_samples, T, True, x[traj].contiguous(), content[traj].contiguous(), sel)
+        return h.view(num_samples, h.size(2), h.size(3), self.n_channels).permute(0, 3, 1, 2), None
+
+    def sample_z_content(self, num_samples, video_len=None):
+        T = video_len if video_len is not None else self.video_length
+        c = np.repeat(np.random.normal(0, 1, (num_samples, self.dim_z_content)).astype(np.float32), T, axis=0)
+        return torch.from_numpy(c).to(self.main[0].weight.device)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("use sample_videos()/sample_images() (the reference never calls forward())")
+
+
+class VideoGeneratorMNIST(VideoGenerator):
+    """28x28 decoder variant (models/mocogan_ode.py:57-111)."""
+
+    mnist = True
+
+    def _init_ode_parts(self, ode_fn, dim_hidden, linear, dim_z, ngf):
+        hid = dim_hidden if dim_hidden else self.dim_z_motion
+        self.ode_fn = ode_fn(dim=self.dim_z_motion, dim_hidden=hid)
+        self.main = self._make_main(dim_z, ngf, self.n_channels, mnist=True)
+        self.linear = self._make_prenet(linear)
+
+
+class VideoGeneratorMNISTODE(VideoGeneratorMNIST):
+    """The class mnist_moco_ode.py:6 imports (models/mocogan_ode.py:114-148)."""
+
+    def _init_ode_parts(self, ode_fn, dim_hidden, linear, dim_z, ngf):
+        super()._init_ode_parts(ode_fn, dim_hidden, linear, dim_z, ngf)
+        hid = dim_hidden if dim_hidden else self.dim_z_motion
+        self.ode_fn = ode_fn(dim=self.dim_z_motion, dim_hidden=hid)   # re-created, as the reference does
+        self.linear = self._make_prenet(linear)
+
+
+# ==================================================================================================================
+# discriminators
+# ==================================================================================================================
+class Noise(nn.Module):
+    """Identity when use_noise is False, which is always the case in stage 3 (models/mocogan.py:20-29)."""
+
+    def __init__(self, use_noise, sigma=0.2):
+        super().__init__()
+        if use_noise:
+            raise NotImplementedError("use_noise=True is never used by the stage-3 scripts")
+        self.use_noise, self.sigma = use_noise, sigma
+
+    def forward(self, x):
+        return x
+
+
+class _DiscFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, strides, training, keep, x, *params):
+        out = plan.forward(training, x=x, x_strides=strides)
+        plan.busy = keep
+        ctx.plan = plan
+        ctx.x_shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        plan = ctx.plan
+        need_x = ctx.needs_input_grad[4]
+        need_p = any(ctx.needs_input_grad[5:])
+        flat, views, g_in = plan.backward(gout, need_input_grad=need_x, need_param_grad=need_p)
+        grads = []
+        if need_p:
+            for wv, gv, bv in views:
+                grads.append(wv)
+                if gv is not None:
+                    grads += [gv, bv]
+        else:
+            grads = [None] * (len(ctx.needs_input_grad) - 5)
+        gx = None
+        if need_x:
+            g = g_in.clone()                               # [N, D, H, W, C] channels-last (plan buffer is reused)
+            gx = g.permute(0, 4, 1, 2, 3) if len(ctx.x_shape) == 5 else g[:, 0].permute(0, 3, 1, 2)
+        return (None, None, None, None, gx, *grads)
+
+
+class _DiscBase(nn.Module):
+    def _specs(self, x_shape):
+        raise NotImplementedError
+
+    def _layer_params(self):
+        out = []
+        mods = list(self.main)
+        for i, m in enumerate(mods):
+            if isinstance(m, (nn.Conv2d, nn.Conv3d)):
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                if isinstance(nxt, (nn.BatchNorm2d, nn.BatchNorm3d)):
+                    out.append(LayerParams(m.weight, nxt.weight, nxt.bias, nxt.running_mean, nxt.running_var,
+                                           nxt.num_batches_tracked))
+                else:
+                    out.append(LayerParams(m.weight))
+        return out
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        if hasattr(self, "_pool"):
+            self._pool.clear()
+        return r
+
+    def forward(self, input):
+        _require_gpu(self.main[1].weight, type(self).__name__)
+        _require_gpu(input, type(self).__name__ + " input")
+        if input.dtype != torch.float32:
+            raise RuntimeError("fp32 input expected")
+        x = input
+        if x.dim() == 5:
+            strides = (x.stride(0), x.stride(2), x.stride(3), x.stride(4), x.stride(1))
+        else:
+            strides = (x.stride(0), 0, x.stride(2), x.stride(3), x.stride(1))
+        key = tuple(x.shape)
+        plan = self._pool.get(key, lambda: ConvStack(self._specs(x.shape), self._layer_params(),
+                                                     self.main[1].weight.device, owns_input=False))
+        params = []
+        for p in self._layer_params():
+            params.append(p.weight)
+            if p.gamma is not None:
+                params += [p.gamma, p.beta]
+        keep = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        out = _DiscFn.apply(plan, strides, self.training, keep, x, *params)      # [B, Do, Ho, Wo, 1]
+        h = out.permute(0, 4, 1, 2, 3)
+        if input.dim() == 4:
+            h = h[:, :, 0]
+        return h.squeeze(), None
+
+
+class PatchImageDiscriminator(_DiscBase):
+    """models/mocogan.py:66-93: Conv2d k4 s2 p1 x4 (C->ndf->2ndf->4ndf->1), BN on layers 2-3, LeakyReLU(0.2)."""
+
+    def __init__(self, n_channels, ndf=64, use_noise=False, noise_sigma=None):
+        super().__init__()
+        self.use_noise, self.n_channels, self.ndf = use_noise, n_channels, ndf
+        self.main = nn.Sequential(
+            Noise(use_noise, sigma=noise_sigma), nn.Conv2d(n_channels, ndf, 4, 2, 1, bias=False),
+            nn.LeakyReLU(0.2, inplace=True),
+            Noise(use_noise, sigma=noise_sigma), nn.Conv2d(ndf, ndf * 2, 4, 2, 1, bias=False), nn.BatchNorm2d(ndf * 2),
+            nn.LeakyReLU(0.2, inplace=True),
+            Noise(use_noise, sigma=noise_sigma), nn.Conv2d(ndf * 2, ndf * 4, 4, 2, 1, bias=False),
+            nn.BatchNorm2d(ndf * 4), nn.LeakyReLU(0.2, inplace=True),
+            Noise(use_noise, sigma=noise_sigma), nn.Conv2d(ndf * 4, 1, 4, 2, 1, bias=False))
+        self._pool = _Pool()
+
+    def _specs(self, x_shape):
+        B, Cc, H, W = x_shape
+        ndf = self.ndf
+        chans = [Cc, ndf, ndf * 2, ndf * 4, 1]
+        specs = []
+        for i in range(4):
+            Ho, Wo = conv_out(H, 4, 2, 1), conv_out(W, 4, 2, 1)
+            specs.append(LayerSpec(make_geom(B, chans[i], chans[i + 1], (1, H, W), (1, Ho, Wo), (1, 4, 4), (1, 2, 2),
+                                             (0, 1, 1)), L.FPROP, L.ACT_LRELU if i < 3 else L.ACT_NONE, i in (1, 2)))
+            H, W = Ho, Wo
+        return specs
+
+
+class VideoDiscriminator(_DiscBase):
+    """models/mocogan.py:129-164: Conv3d ksize^3, stride (1,2,2), pad (0,1,1) x4 + a final ksize^3 s1 p0 conv."""
+
+    def __init__(self, n_channels, n_output_neurons=1, bn_use_gamma=True, use_noise=False, noise_sigma=None, ndf=64,
+                 ksize=4):
+        super().__init__()
+        if n_output_neurons != 1:
+            raise NotImplementedError("n_output_neurons != 1 is only used by the categorical discriminator")
+        self.n_channels, self.n_output_neurons, self.use_noise = n_channels, n_output_neurons, use_noise
+        self.bn_use_gamma, self.ndf, self.ksize = bn_use_gamma, ndf, ksize
+        st, pd = (1, 2, 2), (0, 1, 1)
+        self.main = nn.Sequential(
+            Noise(use_noise, sigma=noise_sigma), nn.Conv3d(n_channels, ndf, ksize, stride=st, padding=pd, bias=False),
+            nn.LeakyReLU(0.2, inplace=True),
+            Noise(use_noise, sigma=noise_sigma), nn.Conv3d(ndf, ndf * 2, ksize, stride=st, padding=pd, bias=False),
+            nn.BatchNorm3d(ndf * 2), nn.LeakyReLU(0.2, inplace=True),
+            Noise(use_noise, sigma=noise_sigma), nn.Conv3d(ndf * 2, ndf * 4, ksize, stride=st, padding=pd, bias=False),
+            nn.BatchNorm3d(ndf * 4), nn.LeakyReLU(0.2, inplace=True),
+            Noise(use_noise, sigma=noise_sigma), nn.Conv3d(ndf * 4, ndf * 8, ksize, stride=st, padding=pd, bias=False),
+            nn.BatchNorm3d(ndf * 8), nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv3d(ndf * 8, n_output_neurons, ksize, 1, 0, bias=False))
+        self._pool = _Pool()
+
+    def _specs(self, x_shape):
+        B, Cc, D, H, W = x_shape
+        ndf, k = self.ndf, self.ksize
+        chans = [Cc, ndf, ndf * 2, ndf * 4, ndf * 8]
+        specs = []
+        for i in range(4):
+            Do, Ho, Wo = conv_out(D, k, 1, 0), conv_out(H, k, 2, 1), conv_out(W, k, 2, 1)
+            specs.append(LayerSpec(make_geom(B, chans[i], chans[i + 1], (D, H, W), (Do, Ho, Wo), (k, k, k), (1, 2, 2),
+                                             (0, 1, 1)), L.FPROP, L.ACT_LRELU, i > 0))
+            D, H, W = Do, Ho, Wo
+        Do, Ho, Wo = conv_out(D, k, 1, 0), conv_out(H, k, 1, 0), conv_out(W, k, 1, 0)
+        specs.append(LayerSpec(make_geom(B, chans[4], 1, (D, H, W), (Do, Ho, Wo), (k, k, k), (1, 1, 1), (0, 0, 0)),
+                               L.FPROP, L.ACT_NONE, False))
+        return specs

@@ -1,0 +1,230 @@
+"""The training iteration of mnist_moco_ode.py:113-163 (== ucf_moco_ode.py:115-165) restated as `train_step`, with
+the loss and optimiser lowered to libgode kernels, plus single-node data parallelism: one process per GPU, one RCCL
+all-reduce of a flat fp32 gradient bucket per optimiser step (torch.distributed backend "nccl" is RCCL on ROCm).
+
+The reference has no `train_step` function (the body is inline in train()); the call sequence, the RNG draws and
+the d_iters=2 structure below follow that body line by line.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from .engine import stream_ptr
+from .modules import PatchImageDiscriminator, VideoDiscriminator, VideoGenerator, VideoGeneratorMNISTODE
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# loss
+# ------------------------------------------------------------------------------------------------------------------
+class _BceConstFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        x = logits.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x)
+        op = L.BceOp(logits=x.data_ptr(), grad=grad.data_ptr(), loss=loss.data_ptr(), n=x.numel(), target=float(target),
+                     gscale=1.0, accumulate=0)
+        L.run_one(op, stream_ptr())
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return grad * gout, None
+
+
+def bce_with_logits_const(logits: torch.Tensor, target: float) -> torch.Tensor:
+    """nn.BCEWithLogitsLoss()(logits, full_like(logits, target)) -- mean reduction (mnist_moco_ode.py:89,126-128)."""
+    if not logits.is_cuda:
+        raise RuntimeError("bce_with_logits_const runs only on the GPU through libgode.so")
+    return _BceConstFn.apply(logits, target)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# optimiser
+# ------------------------------------------------------------------------------------------------------------------
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(lr, betas, eps, weight_decay) semantics (L2-coupled decay, parameters whose .grad is None
+    are skipped -- the generator's dead GRU cell, models/mocogan.py:198) on libgode's Adam kernel.  state_dict()
+    uses torch.optim.Adam's keys (step / exp_avg / exp_avg_sq) so checkpoints interchange."""
+
+    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8, weight_decay=1e-5):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None, grads: Optional[dict] = None, gscale: float = 1.0):
+        """grads: optional {param: tensor} overriding .grad (views into an all-reduced bucket); gscale multiplies
+        every gradient (1/world_size for data parallelism)."""
+        assert closure is None
+        ops = []
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                g = grads.get(p) if grads is not None else p.grad
+                if g is None:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("FusedAdam runs only on the GPU through libgode.so")
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                ops.append(L.AdamOp(p=p.data_ptr(), g=g.data_ptr(), m=st["exp_avg"].data_ptr(),
+                                    v=st["exp_avg_sq"].data_ptr(), n=p.numel(), lr=group["lr"], beta1=b1, beta2=b2,
+                                    eps=group["eps"], weight_decay=group["weight_decay"], gscale=gscale,
+                                    step=int(st["step"].item())))
+                ops[-1]._keep = g
+        if ops:
+            L.Program(ops).run(stream_ptr())
+        return None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# data parallel gradient bucket
+# ------------------------------------------------------------------------------------------------------------------
+class GradBucket:
+    """Flat fp32 bucket over the parameters of ONE network that received a gradient.  gather() packs the grads,
+    all_reduce() sums them over the process group (one collective per optimiser step; RCCL over xGMI on the GPU box,
+    gloo in the CPU tests), views() hands the reduced slices to the optimiser without copying back."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter]):
+        self.params = [p for p in params]
+        self.flat = None
+        self.live = []
+
+    def gather(self):
+        self.live = [p for p in self.params if p.grad is not None]
+        if not self.live:
+            return None
+        n = sum(p.numel() for p in self.live)
+        if self.flat is None or self.flat.numel() != n or self.flat.device != self.live[0].device:
+            self.flat = torch.empty(n, dtype=torch.float32, device=self.live[0].device)
+        off = 0
+        for p in self.live:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.grad.reshape(-1))
+            off += k
+        return self.flat
+
+    def all_reduce(self, group=None):
+        if self.flat is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+
+    def views(self):
+        out, off = {}, 0
+        for p in self.live:
+            k = p.numel()
+            out[p] = self.flat[off:off + k].view_as(p)
+            off += k
+        return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the iteration
+# ------------------------------------------------------------------------------------------------------------------
+def build_mnist(ngf=64, ndf=64):
+    """The three networks of mnist_moco_ode.py:75-78."""
+    return VideoGeneratorMNISTODE(1, 50, 0, 16, 16, ngf=ngf), VideoDiscriminator(1, ksize=2, ndf=ndf), \
+        PatchImageDiscriminator(1, ndf=ndf)
+
+
+def build_ucf(ngf=64, ndf=64):
+    """ucf_moco_ode.py:77-80 with dim_hidden=16 (the shipped call omits it and raises)."""
+    return VideoGenerator(3, 50, 0, 16, 16, dim_hidden=16, ngf=ngf), VideoDiscriminator(3, ndf=ndf), \
+        PatchImageDiscriminator(3, ndf=ndf)
+
+
+class GanTrainer:
+    """Owns the three networks and their optimisers; step() is one outer iteration of the reference loop."""
+
+    def __init__(self, gen, dis_vid, dis_img, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5, d_iters=2,
+                 process_group=None, freeze_d_in_g_step=True):
+        self.gen, self.dis_vid, self.dis_img = gen, dis_vid, dis_img
+        mk = lambda m: FusedAdam(m.parameters(), lr=lr, betas=betas, weight_decay=weight_decay)  # noqa: E731
+        self.gen_opt, self.vid_opt, self.img_opt = mk(gen), mk(dis_vid), mk(dis_img)
+        self.d_iters, self.group = d_iters, process_group
+        self.freeze_d = freeze_d_in_g_step
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.buckets = {id(m): GradBucket(list(m.parameters())) for m in (gen, dis_vid, dis_img)}
+
+    def _opt_step(self, model, opt):
+        if self.world > 1:
+            b = self.buckets[id(model)]
+            b.gather()
+            b.all_reduce(self.group)
+            opt.step(grads=b.views(), gscale=1.0 / self.world)
+        else:
+            opt.step()
+
+    def d_image_step(self, real_img):
+        B = real_img.shape[0]
+        self.img_opt.zero_grad()
+        pr, _ = self.dis_img(real_img)
+        with torch.no_grad():
+            fake, _ = self.gen.sample_images(B)
+        pf, _ = self.dis_img(fake)
+        loss = bce_with_logits_const(pr, 1.0) + bce_with_logits_const(pf, 0.0)
+        loss.backward()
+        self._opt_step(self.dis_img, self.img_opt)
+        return loss.detach()
+
+    def d_video_step(self, real_vid):
+        B = real_vid.shape[0]
+        self.vid_opt.zero_grad()
+        pr, _ = self.dis_vid(real_vid.transpose(1, 2))          # [B,T,C,H,W] -> [B,C,T,H,W] view, read in place
+        with torch.no_grad():
+            fake, _ = self.gen.sample_videos(B)
+        pf, _ = self.dis_vid(fake)
+        loss = bce_with_logits_const(pr, 1.0) + bce_with_logits_const(pf, 0.0)
+        loss.backward()
+        self._opt_step(self.dis_vid, self.vid_opt)
+        return loss.detach()
+
+    def g_step(self, B):
+        self.gen_opt.zero_grad()
+        frozen = []
+        if self.freeze_d:
+            # the reference lets this backward also fill the discriminators' .grad, which the next zero_grad()
+            # discards unused (mnist_moco_ode.py:116,134,162); skipping those weight-gradient GEMMs changes nothing
+            for m in (self.dis_vid, self.dis_img):
+                for p in m.parameters():
+                    if p.requires_grad:
+                        p.requires_grad_(False)
+                        frozen.append(p)
+        try:
+            fake_vid, _ = self.gen.sample_videos(B)
+            fake_img, _ = self.gen.sample_images(B)
+            pv, _ = self.dis_vid(fake_vid)
+            pi, _ = self.dis_img(fake_img)
+            loss = bce_with_logits_const(pv, 1.0) + bce_with_logits_const(pi, 1.0)
+            loss.backward()
+        finally:
+            for p in frozen:
+                p.requires_grad_(True)
+        self._opt_step(self.gen, self.gen_opt)
+        return loss.detach()
+
+    def step(self, real_imgs: Sequence[torch.Tensor], real_vids: Sequence[torch.Tensor]):
+        """real_imgs[i]: [B,C,H,W], real_vids[i]: [B,T,C,H,W] for i < d_iters.  Returns the three losses of the last
+        inner pass as device scalars (the reference prints them every 100 iterations)."""
+        B = real_imgs[0].shape[0]
+        li = lv = None
+        for i in range(self.d_iters):
+            li = self.d_image_step(real_imgs[i])
+            lv = self.d_video_step(real_vids[i])
+        lg = self.g_step(B)
+        return li, lv, lg
+
+
+def train_step(trainer: GanTrainer, real_imgs, real_vids):
+    """Functional spelling of GanTrainer.step for parity tests that read like oracle.mocogan_ref.train_step."""
+    return trainer.step(real_imgs, real_vids)

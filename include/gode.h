@@ -1,0 +1,183 @@
+/* gode.h -- C ABI of libgode.so, the MI355X (gfx950) native library behind the MoCoGAN + Neural-ODE hot path.
+ *
+ * The reference (chechaohp/gan-ode) is pure Python on PyTorch and has no FFI of its own; its seam for this path is
+ * the class surface imported by mnist_moco_ode.py:5-6 / ucf_moco_ode.py:5-6.  The Python host code in
+ * gan-ode_amd/ mirrors that surface and lowers every call to the entry points below through ctypes.  Each entry
+ * point cites the reference arithmetic it replaces.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (PyTorch's allocator);
+ *    the library never allocates, frees or keeps memory and has no mutable global state;
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*) and never synchronises;
+ *  - return value: 0 ok, <0 argument error (GODE_E_*), >0 a hipError_t from a launch;
+ *  - activations are channels-last fp32: [N][D][H][W][C]; weights stay in PyTorch's canonical layout
+ *    W[co][ci][kd][kh][kw] (Conv) == W[in][out][kh][kw] (ConvTranspose, seen as the conv whose dgrad it is) and
+ *    are re-packed on the device by gode_pack_* into the K-contiguous panels the GEMM kernels read.
+ */
+#ifndef GODE_H
+#define GODE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GODE_VERSION 100
+
+enum { GODE_OK = 0, GODE_E_ARG = -1, GODE_E_SHAPE = -2, GODE_E_KIND = -3 };
+enum { GODE_ACT_NONE = 0, GODE_ACT_RELU = 1, GODE_ACT_LRELU = 2,              /* LeakyReLU slope is 0.2 */
+       GODE_ACT_TANH_OUT = 3 /* bn_bwd only: y holds tanh OUTPUT, g *= 1-y^2 */ };
+enum { GODE_EPI_RAW = 0, GODE_EPI_TANH = 1 };
+enum { GODE_FPROP = 0, GODE_DGRAD = 1 };
+
+/* A regular convolution x[N,Di,Hi,Wi,Ci] -> y[N,Do,Ho,Wo,Co].  2-D layers use D=1,kd=1,sd=1,pd=0.  A
+ * ConvTranspose layer is described by the convolution whose data-gradient it is (x = its output). */
+typedef struct gode_conv_geom {
+  int32_t N, Ci, Co;
+  int32_t Di, Hi, Wi;
+  int32_t Do, Ho, Wo;
+  int32_t kd, kh, kw;
+  int32_t sd, sh, sw;
+  int32_t pd, ph, pw; /* may be negative (ConvTranspose k=1,p=2 of mocogan_ode.py:82 is a crop) */
+} gode_conv_geom;
+
+/* ---- implicit-GEMM convolution (fp32 MFMA 32x32x2) ---------------------------------------------------------
+ * dir=GODE_FPROP: out=y, gathers x.  dir=GODE_DGRAD: out=x, gathers y (one sub-GEMM per stride phase; this is
+ * the ConvTranspose2d forward of models/mocogan.py:200-215 and the Conv3d/Conv2d input-gradient).
+ * The gathered operand is read through element strides gs[5] = {N,D,H,W,C} (lets the first discriminator layer
+ * read the caller's [B,C,T,H,W] / transposed views in place, mnist_moco_ode.py:136-139) and transformed on load:
+ *   a = act(v*scale[c] + shift[c])   (train-mode BatchNorm + ReLU/LeakyReLU of the PREVIOUS layer; nullable).
+ * Zero padding is applied after the transform.  `wpack` comes from gode_pack_weights for the same geom/dir.
+ * If stats != NULL, per-column partial sums (sum, sum of squares) of the raw outputs are written to
+ * stats[row][2][ncols] (row = m-block, deterministic), feeding gode_bn_finalize. */
+typedef struct gode_igemm_op {
+  gode_conv_geom g;
+  int32_t dir, act, epilogue, tile; /* tile: 0 auto */
+  const float* src;
+  const float* wpack;
+  float* out;
+  const float* scale;
+  const float* shift;
+  float* stats;
+  int64_t gs[5];
+} gode_igemm_op;
+int gode_igemm(const gode_igemm_op* op, void* stream);
+/* number of partial-stats rows gode_igemm writes for this op (host-side, no GPU work) */
+int gode_igemm_stats_rows(const gode_igemm_op* op);
+/* floats needed for the packed weights of (geom, dir) */
+int64_t gode_pack_size(const gode_conv_geom* g, int dir);
+/* canonical W[co][ci][taps] -> packed panels.  co_perm (nullable, length g->Co): internal y-side channel c is
+ * canonical output channel co_perm[c] (zero weights when co_perm[c] < 0); g->Co counts INTERNAL channels.  Used for
+ * the generator's first layer, whose latent buffer is stored [motion 16|content 50|pad 6] while the reference
+ * concatenates content first (models/mocogan.py:267). */
+int gode_pack_weights(const gode_conv_geom* g, int dir, const float* w, float* wpack, const int32_t* co_perm,
+                      int32_t co_canon, void* stream);
+
+/* ---- weight gradient: dW[co][ci][taps] = sum_m y_grad[m][co] * act(x*scale+shift)[pos(m,tap)][ci] ----------
+ * split over the reduction (output positions) into `splits` slabs of a workspace, then reduced deterministically
+ * and scattered into the canonical layout (accumulate!=0 adds to dW).  xform_on_y!=0 applies the transform to
+ * the y-side operand instead (ConvTranspose layers: their *input* is the y side). */
+typedef struct gode_wgrad_op {
+  gode_conv_geom g;
+  int32_t act, xform_on_y, splits, accumulate;
+  const float* x;  /* x side tensor (channels-last unless xs given) */
+  const float* y;  /* y side tensor, channels-last */
+  const float* scale;
+  const float* shift;
+  float* work;     /* >= gode_wgrad_work_size floats */
+  float* dw;       /* canonical layout */
+  const int32_t* co_perm; int64_t co_canon; /* as in gode_pack_weights, nullable / g.Co */
+  int64_t xs[5];   /* element strides of x {N,D,H,W,C}; all zero = channels-last contiguous */
+} gode_wgrad_op;
+int gode_wgrad(const gode_wgrad_op* op, void* stream);
+int64_t gode_wgrad_work_size(const gode_wgrad_op* op);
+int gode_wgrad_auto_splits(const gode_conv_geom* g);
+
+/* ---- BatchNorm (train mode: batch statistics, eps, momentum as nn.BatchNorm2d/3d defaults) ------------------
+ * finalize: partial sums -> mean, invstd, and the fused affine scale=gamma*invstd, shift=beta-mean*scale that the
+ * NEXT layer's operand load applies; updates running_mean/var (unbiased var) and num_batches_tracked.
+ * training==0: scale/shift from the running statistics (genSamples' eval mode, mnist_moco_ode.py:31-35). */
+typedef struct gode_bn_finalize_op {
+  const float* stats; int32_t rows, ncols, C; int64_t count;
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* mean; float* invstd; float* scale; float* shift;
+  float momentum, eps; int32_t training, pad_;
+} gode_bn_finalize_op;
+int gode_bn_finalize(const gode_bn_finalize_op* op, void* stream);
+
+/* backward of y -> BN -> act given g_a = dL/d(act output), all [M][C] channels-last:
+ *   g_z = g_a * act'(scale*y+shift);  dbeta = sum g_z;  dgamma = sum g_z*xhat;
+ *   g_y = gamma*invstd*(g_z - dbeta/M - xhat*dgamma/M)     written in place over g_a.
+ * With mean==NULL the layer has no BN: g_y = g_a*act'(y).  work: >= 2*C*rows floats (rows = ceil(M/1024)).
+ * accumulate!=0 adds into dgamma/dbeta. */
+typedef struct gode_bn_bwd_op {
+  float* g; const float* y; int64_t M; int32_t C, act;
+  const float* gamma; const float* mean; const float* invstd; const float* scale; const float* shift;
+  float* dgamma; float* dbeta; float* work; int32_t accumulate, pad_;
+} gode_bn_bwd_op;
+int gode_bn_bwd(const gode_bn_bwd_op* op, void* stream);
+int64_t gode_bn_bwd_work_size(int64_t M, int32_t C);
+
+/* ---- motion-latent ODE (models/mocogan_ode.py:6-17,123-148; torchdiffeq fixed-grid rk4 = Kutta 3/8) --------
+ * forward: x[N][16] host-drawn noise -> pre-net Linear(16,64)/LReLU/Linear(64,16)/LReLU -> T-1 RK4(3/8) steps
+ * of f(y)=W2 tanh(W1 y+b1)+b2 with step sizes dt[T-1] -> latent rows.  z is the generator's latent buffer
+ * [rows][72] = [motion 16 | content 50 | zero pad 6]; row n*T+t (sel_t==NULL) or row n holding time sel_t[n]
+ * (sample_images' row selection, models/mocogan.py:287-295).  content[N][50] is broadcast over the T rows.
+ * traj[N][T][16] (nullable) keeps the whole trajectory for the adjoint pass. */
+typedef struct gode_ode_params {
+  const float* Wa; const float* ba; const float* Wb; const float* bb; /* pre-net: [64,16],[64],[16,64],[16] */
+  const float* W1; const float* b1; const float* W2; const float* b2; /* ODEFunc: [16,16],[16],[16,16],[16] */
+} gode_ode_params;
+typedef struct gode_ode_fwd_op {
+  gode_ode_params p;
+  const float* x; const float* content; const float* dt; const int32_t* sel_t;
+  float* z; float* traj; int32_t N, T, substeps, prenet; /* prenet==0: linear=False (nn.Identity) */
+} gode_ode_fwd_op;
+int gode_ode_fwd(const gode_ode_fwd_op* op, void* stream);
+/* adjoint backward (torchdiffeq odeint_adjoint semantics: per output interval ONE reverse-time RK4(3/8) step of
+ * (y, a, g_theta), y reset to the stored trajectory, a += upstream grad) followed by the pre-net backward.
+ * gz[rows][72]: gradient wrt the latent rows (only the 16 motion columns are read).  Parameter gradients are
+ * reduced deterministically through work (>= gode_ode_bwd_work_size floats) and written (accumulate!=0: added) to
+ * grads, laid out as the 8 tensors of gode_ode_params in order (2672 floats). */
+typedef struct gode_ode_bwd_op {
+  gode_ode_params p;
+  const float* x; const float* traj; const float* dt; const int32_t* sel_t; const float* gz;
+  float* work; float* grads; int32_t N, T, substeps, prenet, accumulate, pad_;
+} gode_ode_bwd_op;
+int gode_ode_bwd(const gode_ode_bwd_op* op, void* stream);
+int64_t gode_ode_bwd_work_size(int32_t N);
+#define GODE_ODE_NPARAM 2672
+
+/* ---- loss and optimiser (mnist_moco_ode.py:86-89) ------------------------------------------------------------
+ * BCE-with-logits, mean reduced, constant target: loss (+)= mean(max(x,0) - x*t + log1p(exp(-|x|))) and
+ * g[i] = gscale*(sigmoid(x[i]) - t)/n.  loss is one device float; accumulate!=0 adds to it. */
+typedef struct gode_bce_op {
+  const float* logits; float* grad; float* loss; int64_t n; float target, gscale; int32_t accumulate, pad_;
+} gode_bce_op;
+int gode_bce_logits(const gode_bce_op* op, void* stream);
+/* torch.optim.Adam with L2-coupled weight_decay on one tensor: g+=wd*p; m,v update; bias-corrected step. */
+typedef struct gode_adam_op {
+  float* p; const float* g; float* m; float* v; int64_t n;
+  float lr, beta1, beta2, eps, weight_decay, gscale; int32_t step, pad_; /* step >= 1; gscale: 1/world for DP */
+} gode_adam_op;
+int gode_adam_l2(const gode_adam_op* op, void* stream);
+
+/* out[i] = a[i]*alpha (+ out[i] if accumulate); small utility for gradient bucket handling */
+int gode_scale(float* out, const float* a, int64_t n, float alpha, int accumulate, void* stream);
+
+/* ---- program runner: executes n ops back to back on the stream (one host call per network pass) -------------*/
+enum { GODE_OP_IGEMM = 1, GODE_OP_WGRAD = 2, GODE_OP_BN_FINALIZE = 3, GODE_OP_BN_BWD = 4, GODE_OP_ODE_FWD = 5,
+       GODE_OP_ODE_BWD = 6, GODE_OP_BCE = 7, GODE_OP_ADAM = 8, GODE_OP_PACK = 9 };
+typedef struct gode_pack_op {
+  gode_conv_geom g; int32_t dir, co_canon; const float* w; float* wpack; const int32_t* co_perm;
+} gode_pack_op;
+int gode_run(const int32_t* kinds, const void* const* ops, int32_t n, void* stream);
+
+int gode_version(void);
+/* size of every op struct as compiled, so the ctypes mirror can assert it matches (index = GODE_OP_*) */
+int gode_sizeof(int kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,333 @@
+"""GPU: every libgode entry point called through the C ABI (ctypes) and compared with the CPU oracle
+(torch CPU functional ops / oracle.ode_ref) on the same seeded inputs.  Tolerance: north_star's 1e-4 relative
+(fp32); gradients through long reductions get 2e-4."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden, rel_err
+
+import gan_ode_amd._lib as L
+from gan_ode_amd.engine import conv_out, make_geom
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev(t):
+    return t.cuda()
+
+
+def cl(t):
+    return t.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def uncl(t):
+    return t.permute(0, 4, 1, 2, 3)
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pack(g, direction, w, perm=None):
+    lib = L.lib()
+    n = lib.gode_pack_size(C.byref(g), direction)
+    assert n > 0
+    wp = torch.empty(n, device="cuda")
+    L.check(lib.gode_pack_weights(C.byref(g), direction, w.data_ptr(), wp.data_ptr(),
+                                  None if perm is None else perm.data_ptr(), 0, stream()))
+    return wp
+
+
+def igemm(g, direction, src, w, out_dims, scale=None, shift=None, act=L.ACT_NONE, epi=L.EPI_RAW, strides=None,
+          tile=0, want_stats=False, perm=None):
+    lib = L.lib()
+    wp = pack(g, direction, w, perm)
+    out = torch.full(out_dims, float("nan"), device="cuda")
+    op = L.IgemmOp(g=g, dir=direction, act=act, epilogue=epi, tile=tile, src=src.data_ptr(), wpack=wp.data_ptr(),
+                   out=out.data_ptr(), scale=None if scale is None else scale.data_ptr(),
+                   shift=None if shift is None else shift.data_ptr())
+    if strides is not None:
+        for i in range(5):
+            op.gs[i] = strides[i]
+    stats = None
+    if want_stats:
+        rows = lib.gode_igemm_stats_rows(C.byref(op))
+        stats = torch.full((rows, 2, out_dims[-1] if direction == L.FPROP else out_dims[-1]), float("nan"), device="cuda")
+        op.stats = stats.data_ptr()
+    L.run_one(op, stream())
+    torch.cuda.synchronize()
+    return out, stats
+
+
+CASES = [
+    # (Ci, Co, (Di,Hi,Wi), k, s, p, N)
+    (1, 8, (16, 28, 28), (2, 2, 2), (1, 2, 2), (0, 1, 1), 3),
+    (8, 16, (15, 15, 15), (2, 2, 2), (1, 2, 2), (0, 1, 1), 3),
+    (64, 128, (15, 15, 15), (2, 2, 2), (1, 2, 2), (0, 1, 1), 2),   # full-width MNIST video-D layer 1
+    (16, 1, (12, 3, 3), (2, 2, 2), (1, 1, 1), (0, 0, 0), 5),
+    (3, 8, (6, 16, 16), (4, 4, 4), (1, 2, 2), (0, 1, 1), 2),
+    (32, 64, (1, 8, 8), (1, 4, 4), (1, 2, 2), (0, 1, 1), 9),
+    (128, 256, (1, 8, 8), (1, 4, 4), (1, 2, 2), (0, 1, 1), 40),    # 128x128 tile path, several m-blocks
+    (1, 8, (1, 28, 28), (1, 1, 1), (1, 1, 1), (0, 2, 2), 4),
+    (12, 1, (1, 3, 3), (1, 4, 4), (1, 2, 2), (0, 1, 1), 7),
+    (5, 7, (3, 7, 9), (3, 2, 2), (1, 3, 2), (1, 1, 0), 2),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_igemm_fprop_dgrad_wgrad(case):
+    Ci, Co, xi, k, s, p, N = case
+    yo = tuple(conv_out(xi[a], k[a], s[a], p[a]) for a in range(3))
+    g = make_geom(N, Ci, Co, xi, yo, k, s, p)
+    gen = torch.Generator().manual_seed(abs(hash(case)) % 997)
+    x = torch.randn(N, Ci, *xi, generator=gen)
+    w = torch.randn(Co, Ci, *k, generator=gen) * 0.2
+    gy = torch.randn(N, Co, *yo, generator=gen)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv3d(xr, wr, stride=s, padding=p)
+    y_ref.backward(gy)
+    # FPROP (channels-last source) + BN partial statistics
+    out, stats = igemm(g, L.FPROP, dev(cl(x)), dev(w), (N, *yo, Co), want_stats=True)
+    assert rel_err(uncl(out).cpu(), y_ref.detach()) < TOL
+    flat = y_ref.detach().permute(0, 2, 3, 4, 1).reshape(-1, Co).double()
+    assert rel_err(stats[:, 0].double().sum(0).cpu(), flat.sum(0)) < TOL
+    assert rel_err(stats[:, 1].double().sum(0).cpu(), (flat * flat).sum(0)) < TOL
+    # FPROP reading the NCDHW tensor in place
+    xd = dev(x)
+    st = (xd.stride(0), xd.stride(2), xd.stride(3), xd.stride(4), xd.stride(1))
+    out2, _ = igemm(g, L.FPROP, xd, dev(w), (N, *yo, Co), strides=st)
+    assert rel_err(out2.cpu(), out.cpu()) < 1e-6
+    # DGRAD
+    gx, _ = igemm(g, L.DGRAD, dev(cl(gy)), dev(w), (N, *xi, Ci))
+    assert rel_err(uncl(gx).cpu(), xr.grad) < TOL
+    # WGRAD
+    lib = L.lib()
+    dw = torch.full_like(w, float("nan")).cuda()
+    xc, gyc = dev(cl(x)), dev(cl(gy))
+    op = L.WgradOp(g=g, act=L.ACT_NONE, xform_on_y=0, splits=0, accumulate=0, x=xc.data_ptr(), y=gyc.data_ptr(),
+                   dw=dw.data_ptr())
+    work = torch.empty(lib.gode_wgrad_work_size(C.byref(op)), device="cuda")
+    op.work = work.data_ptr()
+    L.run_one(op, stream())
+    assert rel_err(dw.cpu(), wr.grad) < 2e-4
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+def test_igemm_all_tiles_with_fused_bn_relu(tile):
+    """Every tile configuration, with the previous layer's BatchNorm+ReLU fused into the operand load and zero
+    padding applied AFTER the transform."""
+    N, Ci, Co, hw = 5, 24, 40, 9
+    g = make_geom(N, Ci, Co, (1, hw, hw), (1, 5, 5), (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    gen = torch.Generator().manual_seed(tile)
+    x = torch.randn(N, Ci, 1, hw, hw, generator=gen)
+    w = torch.randn(Co, Ci, 1, 3, 3, generator=gen) * 0.1
+    sc, sh = torch.rand(Ci, generator=gen) + 0.5, torch.randn(Ci, generator=gen)
+    a = F.relu(x * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1))
+    y_ref = F.conv3d(a, w, stride=(1, 2, 2), padding=(0, 1, 1))
+    out, _ = igemm(g, L.FPROP, dev(cl(x)), dev(w), (N, 1, 5, 5, Co), scale=dev(sc), shift=dev(sh), act=L.ACT_RELU,
+                   tile=tile)
+    assert rel_err(uncl(out).cpu(), y_ref) < TOL
+    # tanh epilogue on the transposed direction
+    gy = torch.randn(N, Co, 1, 5, 5, generator=gen)
+    ref = torch.tanh(F.conv_transpose3d(gy, w, stride=(1, 2, 2), padding=(0, 1, 1)))
+    gx, _ = igemm(g, L.DGRAD, dev(cl(gy)), dev(w), (N, 1, hw, hw, Ci), epi=L.EPI_TANH, tile=tile)
+    assert rel_err(uncl(gx).cpu(), ref) < TOL
+
+
+def test_wgrad_transform_on_either_side_and_accumulate():
+    N, Ci, Co = 6, 8, 16
+    g = make_geom(N, Ci, Co, (1, 8, 8), (1, 4, 4), (1, 4, 4), (1, 2, 2), (0, 1, 1))
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Ci, 1, 8, 8, generator=gen)
+    y = torch.randn(N, Co, 1, 4, 4, generator=gen)
+    lib = L.lib()
+    for on_y in (0, 1):
+        Cx = Co if on_y else Ci
+        sc, sh = torch.rand(Cx, generator=gen) + 0.5, torch.randn(Cx, generator=gen)
+        if on_y:
+            xa, ya = x, F.leaky_relu(y * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1), 0.2)
+        else:
+            xa, ya = F.leaky_relu(x * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1), 0.2), y
+        wr = torch.zeros(Co, Ci, 1, 4, 4, requires_grad=True)
+        F.conv3d(xa, wr, stride=(1, 2, 2), padding=(0, 1, 1)).backward(ya)
+        base = torch.randn(Co, Ci, 1, 4, 4, generator=gen)
+        dw = base.clone().cuda()
+        xc, yc, scd, shd = dev(cl(x)), dev(cl(y)), dev(sc), dev(sh)
+        op = L.WgradOp(g=g, act=L.ACT_LRELU, xform_on_y=on_y, splits=3, accumulate=1, x=xc.data_ptr(), y=yc.data_ptr(),
+                       scale=scd.data_ptr(), shift=shd.data_ptr(), dw=dw.data_ptr())
+        work = torch.empty(lib.gode_wgrad_work_size(C.byref(op)), device="cuda")
+        op.work = work.data_ptr()
+        L.run_one(op, stream())
+        assert rel_err(dw.cpu() - base, wr.grad) < 2e-4
+
+
+def test_bn_finalize_and_backward():
+    M, Cc = 3000, 32
+    gen = torch.Generator().manual_seed(9)
+    y = torch.randn(M, Cc, generator=gen) * 2 + 1
+    ga = torch.randn(M, Cc, generator=gen)
+    bn = torch.nn.BatchNorm1d(Cc)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=gen); bn.bias.normal_(generator=gen)
+    yr = y.clone().requires_grad_(True)
+    out = F.leaky_relu(bn(yr), 0.2)
+    out.backward(ga)
+    # statistics as the GEMM epilogue would deliver them: rows of partial (sum, sumsq)
+    rows = 7
+    chunks = torch.chunk(y, rows)
+    stats = torch.stack([torch.stack([c.sum(0), (c * c).sum(0)]) for c in chunks]).cuda()
+    d = {k: torch.empty(Cc, device="cuda") for k in ("mean", "invstd", "scale", "shift")}
+    rm, rv, nbt = torch.zeros(Cc).cuda(), torch.ones(Cc).cuda(), torch.zeros((), dtype=torch.int64).cuda()
+    gam, bet = dev(bn.weight.detach()), dev(bn.bias.detach())
+    op = L.BnFinalizeOp(stats=stats.data_ptr(), rows=rows, ncols=Cc, C=Cc, count=M, gamma=gam.data_ptr(), beta=bet.data_ptr(),
+                        running_mean=rm.data_ptr(), running_var=rv.data_ptr(), num_batches_tracked=nbt.data_ptr(),
+                        mean=d["mean"].data_ptr(), invstd=d["invstd"].data_ptr(), scale=d["scale"].data_ptr(),
+                        shift=d["shift"].data_ptr(), momentum=0.1, eps=1e-5, training=1)
+    L.run_one(op, stream())
+    assert rel_err(rm.cpu(), bn.running_mean) < TOL and rel_err(rv.cpu(), bn.running_var) < TOL and int(nbt) == 1
+    yd, g = dev(y), dev(ga)
+    dg, db = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+    work = torch.empty(L.lib().gode_bn_bwd_work_size(M, Cc), device="cuda")
+    bop = L.BnBwdOp(g=g.data_ptr(), y=yd.data_ptr(), M=M, C=Cc, act=L.ACT_LRELU, gamma=gam.data_ptr(),
+                    mean=d["mean"].data_ptr(), invstd=d["invstd"].data_ptr(), scale=d["scale"].data_ptr(),
+                    shift=d["shift"].data_ptr(), dgamma=dg.data_ptr(), dbeta=db.data_ptr(), work=work.data_ptr())
+    L.run_one(bop, stream())
+    assert rel_err(g.cpu(), yr.grad) < TOL
+    assert rel_err(dg.cpu(), bn.weight.grad) < TOL and rel_err(db.cpu(), bn.bias.grad) < TOL
+    # eval mode: scale/shift from running statistics
+    op.training = 0
+    L.run_one(op, stream())
+    bn.eval()
+    ref = bn(y)
+    assert rel_err((yd * d["scale"] + d["shift"]).cpu(), ref.detach()) < TOL
+
+
+def _ode_setup(N, T, seed, prenet=True):
+    from oracle.mocogan_ref import OdeRhs
+    torch.manual_seed(seed)
+    f = OdeRhs(16, 16)
+    pre = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.LeakyReLU(0.2), torch.nn.Linear(64, 16),
+                              torch.nn.LeakyReLU(0.2))
+    x = torch.randn(N, 16)
+    return f, pre, x
+
+
+@pytest.mark.parametrize("N,T,sub", [(8, 16, 1), (37, 16, 1), (5, 8, 1), (20, 16, 3)])
+def test_ode_forward_and_adjoint(N, T, sub):
+    from oracle import ode_ref
+    f, pre, x = _ode_setup(N, T, 100 + N)
+    t = torch.linspace(0, 1, T).float()
+    opts = None if sub == 1 else None
+    # oracle; substeps>1 is the build's own extension: compare with the oracle on the refined grid
+    if sub == 1:
+        grid = t
+    else:
+        grid = torch.cat([t[j] + (t[j + 1] - t[j]) / sub * torch.arange(sub) for j in range(T - 1)] + [t[-1:]])
+    x0 = pre(x)
+    sol_all = ode_ref.odeint_adjoint(f, x0, grid, method="rk4")
+    sol = sol_all[::sub]
+    gsol = torch.randn(T, N, 16, generator=torch.Generator().manual_seed(1))
+    content = torch.randn(N, 50, generator=torch.Generator().manual_seed(2))
+    if sub == 1:
+        sol.backward(gsol)
+        ref_grads = [p.grad for p in list(pre.parameters()) + list(f.parameters())]
+    # device
+    P = [dev(p.detach()) for p in list(pre.parameters()) + list(f.parameters())]
+    op = L.OdeParams(*[p.data_ptr() for p in P])
+    xd, cd = dev(x), dev(content)
+    dt = dev(t[1:] - t[:-1])
+    z = torch.full((N * T, 72), float("nan"), device="cuda")
+    traj = torch.empty(N, T, 16, device="cuda")
+    fop = L.OdeFwdOp(p=op, x=xd.data_ptr(), content=cd.data_ptr(), dt=dt.data_ptr(), sel_t=None, z=z.data_ptr(),
+                     traj=traj.data_ptr(), N=N, T=T, substeps=sub, prenet=1)
+    L.run_one(fop, stream())
+    zz = z.cpu().view(N, T, 72)
+    tol = TOL if sub == 1 else 5e-4   # substeps divide dt in fp32 differently from the refined oracle grid
+    assert rel_err(zz[:, :, :16], sol.detach().transpose(0, 1)) < tol
+    assert torch.equal(zz[:, :, 16:66], content[:, None, :].expand(N, T, 50))
+    assert float(zz[:, :, 66:].abs().max()) == 0.0
+    assert rel_err(traj.cpu(), sol.detach().transpose(0, 1)) < tol
+    if sub != 1:
+        return
+    gz = torch.zeros(N * T, 72, device="cuda")
+    gz.view(N, T, 72)[:, :, :16] = dev(gsol.transpose(0, 1).contiguous())
+    grads = torch.full((L.ODE_NPARAM,), float("nan"), device="cuda")
+    work = torch.empty(L.lib().gode_ode_bwd_work_size(N), device="cuda")
+    bop = L.OdeBwdOp(p=op, x=xd.data_ptr(), traj=traj.data_ptr(), dt=dt.data_ptr(), sel_t=None, gz=gz.data_ptr(),
+                     work=work.data_ptr(), grads=grads.data_ptr(), N=N, T=T, substeps=1, prenet=1, accumulate=0)
+    L.run_one(bop, stream())
+    g = grads.cpu()
+    off = 0
+    for name, r in zip(("Wa", "ba", "Wb", "bb", "W1", "b1", "W2", "b2"), ref_grads):
+        n = r.numel()
+        assert rel_err(g[off:off + n].view_as(r), r) < 2e-4, name
+        off += n
+
+
+def test_ode_golden_fixture_and_row_selection():
+    """ode_rk4.npz (weights, x, solution and adjoint gradients produced with the reference's ODEFunc class) and the
+    sample_images row-selection mode."""
+    g = golden("ode_rk4.npz")
+    N, T = g["x"].shape[0], g["t"].shape[0]
+    names = ["fn.0.weight", "fn.0.bias", "fn.2.weight", "fn.2.bias"]
+    P = [torch.from_numpy(g[f"w/{k}"]).cuda() for k in names]
+    op = L.OdeParams(None, None, None, None, *[p.data_ptr() for p in P])
+    x = torch.from_numpy(g["x"]).cuda()
+    tt = torch.from_numpy(g["t"])
+    dt = (tt[1:] - tt[:-1]).cuda()
+    z = torch.zeros(N * T, 72, device="cuda")
+    traj = torch.empty(N, T, 16, device="cuda")
+    fop = L.OdeFwdOp(p=op, x=x.data_ptr(), content=None, dt=dt.data_ptr(), sel_t=None, z=z.data_ptr(), traj=traj.data_ptr(),
+                     N=N, T=T, substeps=1, prenet=0)
+    L.run_one(fop, stream())
+    assert rel_err(traj.cpu().transpose(0, 1), g["sol"]) < TOL
+    gz = torch.zeros(N * T, 72, device="cuda")
+    gz.view(N, T, 72)[:, :, :16] = torch.from_numpy(g["grad_sol"]).transpose(0, 1).cuda()
+    grads = torch.empty(L.ODE_NPARAM, device="cuda")
+    work = torch.empty(L.lib().gode_ode_bwd_work_size(N), device="cuda")
+    bop = L.OdeBwdOp(p=op, x=x.data_ptr(), traj=traj.data_ptr(), dt=dt.data_ptr(), sel_t=None, gz=gz.data_ptr(),
+                     work=work.data_ptr(), grads=grads.data_ptr(), N=N, T=T, substeps=1, prenet=0, accumulate=0)
+    L.run_one(bop, stream())
+    gg = grads.cpu()
+    for k, o, n in (("fn.0.weight", 2128, 256), ("fn.0.bias", 2384, 16), ("fn.2.weight", 2400, 256), ("fn.2.bias", 2656, 16)):
+        assert rel_err(gg[o:o + n].view(g[f"g/{k}"].shape), g[f"g/{k}"]) < 2e-4, k
+    assert float(gg[:2128].abs().max()) == 0.0
+    # row selection: row n holds time sel[n]
+    sel = torch.tensor([(3 * i) % T for i in range(N)], dtype=torch.int32).cuda()
+    z2 = torch.zeros(N, 72, device="cuda")
+    fop2 = L.OdeFwdOp(p=op, x=x.data_ptr(), content=None, dt=dt.data_ptr(), sel_t=sel.data_ptr(), z=z2.data_ptr(),
+                      traj=traj.data_ptr(), N=N, T=T, substeps=1, prenet=0)
+    L.run_one(fop2, stream())
+    want = torch.stack([traj[i, int(sel[i])] for i in range(N)])
+    assert torch.equal(z2[:, :16], want)
+
+
+def test_bce_and_adam():
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(32, 11, 2, 2, generator=gen) * 3
+    for tgt in (0.0, 1.0):
+        xr = x.clone().requires_grad_(True)
+        ref = torch.nn.BCEWithLogitsLoss()(xr, torch.full_like(xr, tgt))
+        ref.backward()
+        xd = x.cuda()
+        grad, loss = torch.empty_like(xd), torch.empty((), device="cuda")
+        L.run_one(L.BceOp(logits=xd.data_ptr(), grad=grad.data_ptr(), loss=loss.data_ptr(), n=xd.numel(), target=tgt,
+                          gscale=1.0, accumulate=0), stream())
+        assert rel_err(loss.cpu(), ref.detach()) < 1e-5 and rel_err(grad.cpu(), xr.grad) < 1e-5
+    p = torch.randn(1000, generator=gen)
+    pr = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([pr], lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)
+    pd, m, v = p.cuda(), torch.zeros(1000).cuda(), torch.zeros(1000).cuda()
+    for step in range(1, 4):
+        gr = torch.randn(1000, generator=gen)
+        pr.grad = gr.clone()
+        opt.step()
+        gd = gr.cuda()
+        L.run_one(L.AdamOp(p=pd.data_ptr(), g=gd.data_ptr(), m=m.data_ptr(), v=v.data_ptr(), n=1000, lr=2e-4, beta1=0.5,
+                           beta2=0.999, eps=1e-8, weight_decay=1e-5, gscale=1.0, step=step), stream())
+    assert float((pd.cpu() - pr.detach()).abs().max()) < 1e-6

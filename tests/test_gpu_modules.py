@@ -1,0 +1,179 @@
+"""GPU: the drop-in module surface (sample_videos / sample_images / discriminators / train step) on libgode.so
+against (a) the golden fixtures produced by the reference's own classes and (b) the CPU oracle on identical seeds,
+at tiny widths and at BASELINE.json's full configuration (batch 32, 16x1x28x28, ngf=ndf=64).
+Tolerance: 1e-4 relative fp32 on frames and losses (north_star); parameter gradients 5e-4 (long fp32 reductions in
+a different order); post-Adam weights compared absolutely (Adam normalises the step to ~lr)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, load_sd, rel_err, seed_all
+
+import gan_ode_amd as G
+from oracle import mocogan_ref as M
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+GTOL = 5e-4
+
+
+def _f32(a):
+    return torch.from_numpy(np.asarray(a).astype(np.float32))
+
+
+@pytest.mark.parametrize("tag,mnist,n_vid,n_img", [("mnist_tiny", True, 4, 4), ("ucf_tiny", False, 1, 3)])
+def test_generator_against_reference_fixture(tag, mnist, n_vid, n_img):
+    g = golden(f"gen_{tag}.npz")
+    s = int(g["seed"])
+    gen = (G.VideoGeneratorMNISTODE(1, 50, 0, 16, 16, ngf=8) if mnist
+           else G.VideoGenerator(3, 50, 0, 16, 16, dim_hidden=16, ngf=8))
+    load_sd(gen, g, "w")
+    gen.cuda()
+    seed_all(s + 1)
+    vid, labels = gen.sample_videos(n_vid)
+    seed_all(s + 2)
+    img, _ = gen.sample_images(n_img)
+    assert tuple(vid.shape) == g["videos"].shape and tuple(img.shape) == g["images"].shape
+    assert labels.dtype == torch.float64 and labels.is_cuda and float(labels.abs().sum()) == 0.0
+    assert rel_err(vid.detach().cpu(), g["videos"]) < TOL
+    assert rel_err(img.detach().cpu(), g["images"]) < TOL
+    ((vid * _f32(g["wv"]).cuda()).sum() + (img * _f32(g["wi"]).cuda()).sum()).backward()
+    for k, p in gen.named_parameters():
+        ref = g[f"g/{k}"]
+        if ref.size == 0:
+            assert p.grad is None, k
+        else:
+            assert rel_err(p.grad.cpu(), ref) < GTOL, k
+    for k, v in gen.state_dict().items():
+        if "running_" in k:
+            assert rel_err(v.cpu(), g[f"w_after/{k}"]) < TOL, k
+        if "num_batches" in k:
+            assert int(v) == int(g[f"w_after/{k}"]), k
+    gen.eval()
+    seed_all(s + 4)
+    with torch.no_grad():
+        ev, _ = gen.sample_videos(n_vid)
+    assert rel_err(ev.cpu(), g["videos_eval"]) < TOL
+
+
+@pytest.mark.parametrize("tag,ctor", [
+    ("vid_mnist_tiny", lambda: G.VideoDiscriminator(1, ksize=2, ndf=8)),
+    ("vid_ucf_tiny", lambda: G.VideoDiscriminator(3, ndf=8)),
+    ("img_mnist_tiny", lambda: G.PatchImageDiscriminator(1, ndf=8)),
+    ("img_ucf_tiny", lambda: G.PatchImageDiscriminator(3, ndf=8)),
+])
+def test_discriminator_against_reference_fixture(tag, ctor):
+    g = golden(f"disc_{tag}.npz")
+    dis = load_sd(ctor(), g, "w").cuda()
+    x = _f32(g["x"]).cuda().requires_grad_(True)
+    logits, none = dis(x)
+    assert none is None and tuple(logits.shape) == g["logits"].shape
+    assert rel_err(logits.detach().cpu(), g["logits"]) < TOL
+    loss = G.bce_with_logits_const(logits, 1.0)
+    assert rel_err(loss.detach().cpu(), g["loss"]) < TOL
+    loss.backward()
+    assert rel_err(x.grad.cpu(), g["grad_x"]) < GTOL
+    for k, p in dis.named_parameters():
+        assert rel_err(p.grad.cpu(), g[f"g/{k}"]) < GTOL, k
+    for k, v in dis.state_dict().items():
+        if "running_" in k:
+            assert rel_err(v.cpu(), g[f"w_after/{k}"]) < TOL, k
+
+
+def test_discriminator_reads_transposed_view_in_place():
+    """mnist_moco_ode.py:136-139 feeds real.transpose(1, 2); UCF-shaped data makes that view non-contiguous."""
+    gen = torch.Generator().manual_seed(0)
+    torch.manual_seed(0)
+    dis, ref = G.VideoDiscriminator(3, ndf=8), M.VideoDisc(3, ndf=8)
+    ref.load_state_dict(dis.state_dict())
+    dis.cuda()
+    real = torch.rand(2, 16, 3, 64, 64, generator=gen)
+    out, _ = dis(real.cuda().transpose(1, 2))
+    want, _ = ref(real.transpose(1, 2))
+    assert rel_err(out.detach().cpu(), want.detach()) < TOL
+
+
+@pytest.mark.parametrize("tag,build,obuild,iters", [("mnist_tiny", G.build_mnist, M.build_mnist, 2),
+                                                    ("ucf_tiny", G.build_ucf, M.build_ucf, 1)])
+def test_train_step_against_reference_fixture(tag, build, obuild, iters):
+    g = golden(f"train_{tag}.npz")
+    s = int(g["seed"])
+    gen, dv, di = build(ngf=8, ndf=8)
+    for m, p in ((gen, "gen"), (dv, "vid"), (di, "img")):
+        load_sd(m, g, f"w0/{p}")
+        m.cuda()
+    tr = G.GanTrainer(gen, dv, di)
+    for it in range(iters):
+        imgs = [_f32(g[f"real_img/{it}/{i}"]).cuda() for i in range(2)]
+        vids = [_f32(g[f"real_vid/{it}/{i}"]).cuda() for i in range(2)]
+        seed_all(s + 1 + it)
+        losses = G.train_step(tr, imgs, vids)
+        got = [float(v) for v in losses]
+        assert np.allclose(got, g["losses"][it], rtol=2e-4, atol=0), (got, g["losses"][it])
+    for m, p in ((gen, "gen"), (dv, "vid"), (di, "img")):
+        for k, v in m.state_dict().items():
+            ref = g[f"w1/{p}/{k}"]
+            if v.dtype == torch.int64:
+                assert int(v) == int(ref), k
+            elif "running_" in k:
+                assert rel_err(v.cpu(), ref) < 2e-4, (p, k)
+            else:
+                # after 1-2 Adam steps every weight has moved by ~lr=2e-4; a wrong-sign gradient would show as 4e-4
+                assert float((v.cpu() - torch.from_numpy(ref)).abs().max()) < 6e-5, (p, k)
+    gen.eval()
+    seed_all(s + 50)
+    with torch.no_grad():
+        ev, _ = gen.sample_videos(g["videos_eval"].shape[0])
+    assert rel_err(ev.cpu(), g["videos_eval"]) < 2e-3
+
+
+def test_full_width_mnist_batch32_against_oracle():
+    """BASELINE.json configs[1]: batch 32, 16x1x28x28, ngf=ndf=64 -- one generator pass, both discriminators and all
+    gradients against the CPU oracle on identical weights and seeds."""
+    seed_all(7)
+    gen, dv, di = G.build_mnist()
+    ogen, odv, odi = M.build_mnist()
+    ogen.load_state_dict(gen.state_dict()); odv.load_state_dict(dv.state_dict()); odi.load_state_dict(di.state_dict())
+    gen.cuda(); dv.cuda(); di.cuda()
+    B = 32
+    seed_all(8)
+    vid, _ = gen.sample_videos(B)
+    img, _ = gen.sample_images(B)
+    pv, _ = dv(vid)
+    pi, _ = di(img)
+    loss = G.bce_with_logits_const(pv, 1.0) + G.bce_with_logits_const(pi, 1.0)
+    loss.backward()
+    seed_all(8)
+    rvid, _ = ogen.sample_videos(B)
+    rimg, _ = ogen.sample_images(B)
+    rpv, _ = odv(rvid)
+    rpi, _ = odi(rimg)
+    bce = torch.nn.BCEWithLogitsLoss()
+    rloss = bce(rpv, torch.ones_like(rpv)) + bce(rpi, torch.ones_like(rpi))
+    rloss.backward()
+    assert vid.shape == (B, 1, 16, 28, 28) and pv.shape == (B, 11, 2, 2) and pi.shape == (B,)
+    assert rel_err(vid.detach().cpu(), rvid.detach()) < TOL
+    assert rel_err(img.detach().cpu(), rimg.detach()) < TOL
+    assert rel_err(pv.detach().cpu(), rpv.detach()) < TOL and rel_err(pi.detach().cpu(), rpi.detach()) < TOL
+    assert abs(float(loss) - float(rloss)) / abs(float(rloss)) < TOL
+    for (k, p), (_, q) in zip(list(gen.named_parameters()) + list(dv.named_parameters()) + list(di.named_parameters()),
+                              list(ogen.named_parameters()) + list(odv.named_parameters()) + list(odi.named_parameters())):
+        if q.grad is None:
+            assert p.grad is None, k
+        else:
+            assert rel_err(p.grad.cpu(), q.grad) < 1e-3, k
+    # size-independent properties at full size
+    assert float(vid.abs().max()) <= 1.0
+    seed_all(8)
+    with torch.no_grad():
+        again, _ = gen.sample_videos(B)
+    # BN running stats do not enter train-mode outputs: same seed -> bit-identical frames (deterministic reductions)
+    assert torch.equal(again, vid.detach())
+
+
+def test_cpu_tensors_are_refused():
+    gen, dv, di = G.build_mnist(ngf=8, ndf=8)
+    with pytest.raises(RuntimeError):
+        gen.sample_videos(2)
+    with pytest.raises(RuntimeError):
+        dv(torch.zeros(2, 1, 16, 28, 28))

@@ -1,0 +1,145 @@
+"""CPU: host-side logic of the product -- C-ABI loading/symbols, drop-in construction (same seed -> the reference's
+initial weights, same state_dict keys), refusal of CPU tensors (no fallback path), the host RNG / row-selection
+contract of sample_images, and the data-parallel gradient bucket over gloo with two ranks."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO, golden, seed_all
+
+import gan_ode_amd as G
+from gan_ode_amd import _lib as L
+from oracle import mocogan_ref as M
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = L.lib()                      # also checks every op struct size against the compiled ABI
+    assert lib.gode_version() == 100
+    hdr = open(os.path.join(REPO, "include", "gode.h")).read()
+    declared = set(re.findall(r"\b(gode_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(L.EXPORTS)
+
+
+def test_argument_errors_are_reported_not_crashed():
+    lib = L.lib()
+    bad = L.IgemmOp()                  # null pointers
+    assert lib.gode_igemm(C.byref(bad), None) < 0
+    g = L.ConvGeom(1, 4, 4, 1, 8, 8, 1, 5, 5, 1, 4, 4, 1, 2, 2, 0, 1, 1)   # Ho should be 4: conv relation violated
+    assert lib.gode_pack_size(C.byref(g), L.FPROP) < 0
+
+
+@pytest.mark.parametrize("tag,ctor", [
+    ("mnist_tiny", lambda: G.VideoGeneratorMNISTODE(1, 50, 0, 16, 16, ngf=8)),
+    ("ucf_tiny", lambda: G.VideoGenerator(3, 50, 0, 16, 16, dim_hidden=16, ngf=8)),
+])
+def test_same_seed_gives_the_reference_initial_weights(tag, ctor):
+    g = golden(f"gen_{tag}.npz")
+    seed_all(int(g["seed"]))
+    gen = ctor()
+    sd = gen.state_dict()
+    want = {k[2:] for k in g.files if k.startswith("w/")}
+    assert set(sd.keys()) == want
+    for k, v in sd.items():
+        assert np.array_equal(v.numpy(), g[f"w/{k}"]), k
+    assert [k for k, _ in gen.named_parameters()][:4] == ["recurrent.weight_ih", "recurrent.weight_hh",
+                                                          "recurrent.bias_ih", "recurrent.bias_hh"]
+
+
+def test_discriminator_state_dict_keys_match_reference():
+    for tag, ctor in (("vid_mnist_tiny", lambda: G.VideoDiscriminator(1, ksize=2, ndf=8)),
+                      ("img_ucf_tiny", lambda: G.PatchImageDiscriminator(3, ndf=8))):
+        g = golden(f"disc_{tag}.npz")
+        assert set(ctor().state_dict().keys()) == {k[2:] for k in g.files if k.startswith("w/")}
+
+
+def test_ucf_constructor_fails_like_the_reference_without_dim_hidden():
+    with pytest.raises(TypeError):
+        G.VideoGenerator(3, 50, 0, 16, 16)          # ucf_moco_ode.py:80 as shipped
+
+
+def test_no_cpu_fallback():
+    gen, dv, di = G.build_mnist(ngf=8, ndf=8)
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        gen.sample_videos(2)
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        dv(torch.zeros(2, 1, 16, 28, 28))
+    with pytest.raises(RuntimeError):
+        G.bce_with_logits_const(torch.zeros(3), 1.0)
+    with pytest.raises(RuntimeError):
+        gen.ode_fn(None, torch.zeros(1, 16))
+
+
+def test_sample_images_host_draws_match_oracle_rng_order(monkeypatch):
+    """The pruned sample_images must consume the host RNGs exactly like the reference (NumPy normal -> torch randn ->
+    NumPy choice) and pick the same latent rows."""
+    gen = G.VideoGeneratorMNISTODE(1, 50, 0, 16, 16, ngf=8)
+    captured = {}
+
+    def fake_run(n_traj, T, select, x, content, sel):
+        captured.update(n=n_traj, T=T, select=select, x=x.clone(), content=content.clone(), sel=sel.clone())
+        return torch.zeros(n_traj, 1, 28, 28, 1)
+
+    monkeypatch.setattr(gen, "_run", fake_run)
+    B, T = 5, 16
+    seed_all(123)
+    gen.sample_images(B)
+    after_np, after_t = np.random.rand(), torch.rand(1)
+    # replay of the reference's draw sequence (models/mocogan.py:288-290 via :252 and mocogan_ode.py:136)
+    seed_all(123)
+    content = np.random.normal(0, 1, (B * T * 2, 50)).astype(np.float32)
+    x = torch.randn(B * T * 2, 16)
+    j = np.sort(np.random.choice(B * T * 2 * T, B, replace=False)).astype(np.int64)
+    assert np.random.rand() == after_np and torch.equal(torch.rand(1), after_t)   # generators left in the same state
+    assert captured["select"] and captured["n"] == B
+    assert torch.equal(captured["x"], x[j // T])
+    assert np.array_equal(captured["content"].numpy(), content[j // T])
+    assert np.array_equal(captured["sel"].numpy(), (j % T).astype(np.int32))
+    # and the oracle's z rows agree with that reading: row j of z is (content[j // T], motion(traj j // T, time j % T))
+    seed_all(123)
+    ogen = M.Generator(1, 50, 0, 16, 16, ngf=8)
+    seed_all(123)
+    z, _ = ogen.sample_z_video(B * T * 2)
+    assert np.array_equal(z[j, :50].detach().numpy(), content[j // T])
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2), torch.nn.GRUCell(2, 2))
+    params = list(net.parameters())
+    for i, p in enumerate(params[:4]):                       # the GRU cell (last 4) never gets a gradient
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    b = G.train.GradBucket(params)
+    flat = b.gather()
+    assert flat.numel() == sum(p.numel() for p in params[:4])
+    b.all_reduce()
+    views = b.views()
+    ok = len(views) == 4
+    for i, p in enumerate(params[:4]):
+        ok = ok and torch.equal(views[p], torch.full_like(p, 3.0 * (i + 1)))     # (1 + 2) * (i + 1)
+        ok = ok and views[p].data_ptr() >= flat.data_ptr()                        # views alias the bucket (no copy back)
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_all_reduce_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 500
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
