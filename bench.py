@@ -64,7 +64,8 @@ def _kernel_roofline(gen, reps=30):
     rows = B * T
     per_layer = []
     igemms = [op for op in prog.ops if isinstance(op, L.IgemmOp)]
-    macs_per_row = [66 * 512 * 16, 512 * 256 * 16 * 4, 256 * 128 * 16 * 16, 128 * 64 * 16 * 64, 64 * 28 * 28]
+    # MACs per latent row (= per frame): Cin*Cout*taps*input positions (0.54M, 3 x 33.55M, 0.05M)
+    macs_per_row = [66 * 512 * 16, 512 * 256 * 16 * 16, 256 * 128 * 16 * 64, 128 * 64 * 16 * 256, 64 * 28 * 28]
     names = ["convT0 66->512 (GEMM)", "convT1 512->256 k4s2", "convT2 256->128 k4s2", "convT3 128->64 k4s2",
              "convT4 64->1 k1 + tanh"]
     for op, macs, name in zip(igemms, macs_per_row, names):

@@ -71,13 +71,15 @@ __device__ __forceinline__ float gz_of(float g, float y, float sc, float sh, int
   return g * gode_act_grad(y * sc + sh, act);
 }
 
-// partial[blk][2][C]: sum g_z, sum g_z * xhat   (C % 4 == 0, C/4 <= 256)
+// partial[blk][2][C] (DOUBLE): sum g_z, sum g_z * xhat   (C % 4 == 0, C/4 <= 256).
+// Both sums cancel heavily (signed gradients), and their error is fed back into every element of g_y, so they are
+// accumulated in fp64 end to end; the kernel stays HBM-bound (2 fp64 FMAs per 8 bytes read).
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const gode_bn_bwd_op a) {
   const int C4 = a.C >> 2, tid = threadIdx.x;
   const int rl = 256 / C4;            // row lanes
   const int cl = tid % C4, rlane = tid / C4;
-  __shared__ float red[2][256][4];
-  f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  __shared__ double red[2][256][4];
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   if (rlane < rl) {
     const int c = cl * 4;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c), sh = *reinterpret_cast<const f32x4*>(a.shift + c);
@@ -90,8 +92,8 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const gode_bn_bwd_op
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float gz = gz_of(g[e], y[e], sc[e], sh[e], a.act);
-        s1[e] += gz;
-        s2[e] += gz * ((y[e] - mu[e]) * is[e]);
+        s1[e] += (double)gz;
+        s2[e] += (double)gz * (double)((y[e] - mu[e]) * is[e]);
       }
     }
   }
@@ -99,13 +101,13 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const gode_bn_bwd_op
   for (int e = 0; e < 4; ++e) { red[0][tid][e] = s1[e]; red[1][tid][e] = s2[e]; }
   __syncthreads();
   if (tid < C4) {
-    f32x4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
+    double t1[4] = {0, 0, 0, 0}, t2[4] = {0, 0, 0, 0};
     for (int j = 0; j < rl; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) { t1[e] += red[0][j * C4 + tid][e]; t2[e] += red[1][j * C4 + tid][e]; }
-    float* dst = a.work + (int64_t)blockIdx.x * 2 * a.C;
-    *reinterpret_cast<f32x4*>(dst + tid * 4) = t1;
-    *reinterpret_cast<f32x4*>(dst + a.C + tid * 4) = t2;
+    double* dst = reinterpret_cast<double*>(a.work) + (int64_t)blockIdx.x * 2 * a.C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dst[tid * 4 + e] = t1[e]; dst[a.C + tid * 4 + e] = t2[e]; }
   }
 }
 
@@ -113,10 +115,11 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const gode_bn_bwd_op
 __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const gode_bn_bwd_op a, int rows) {
   const int c = blockIdx.x, tid = threadIdx.x;
   __shared__ double red[2][256];
+  const double* part = reinterpret_cast<const double*>(a.work);
   double s1 = 0.0, s2 = 0.0;
   for (int r = tid; r < rows; r += 256) {
-    s1 += (double)a.work[(int64_t)r * 2 * a.C + c];
-    s2 += (double)a.work[(int64_t)r * 2 * a.C + a.C + c];
+    s1 += part[(int64_t)r * 2 * a.C + c];
+    s2 += part[(int64_t)r * 2 * a.C + a.C + c];
   }
   red[0][tid] = s1; red[1][tid] = s2;
   __syncthreads();
@@ -131,25 +134,28 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const gode_bn_bwd_
     const double invM = 1.0 / (double)a.M;
     const double g = a.gamma ? (double)a.gamma[c] : 1.0, is = (double)a.invstd[c], mu = (double)a.mean[c];
     const double k = g * is;
-    float* coef = a.work + (int64_t)rows * 2 * a.C;
-    coef[c] = (float)k;                                                              // * g_z
-    coef[a.C + c] = (float)(-k * is * red[1][0] * invM);                             // * y
-    coef[2 * a.C + c] = (float)(-k * red[0][0] * invM + k * is * red[1][0] * invM * mu);  // constant
+    float* coef = a.work + (int64_t)rows * 4 * a.C;
+    coef[c] = (float)k;                                   // * g_z
+    coef[a.C + c] = (float)(k * is * red[1][0] * invM);   // * (mean - y)
+    coef[2 * a.C + c] = (float)(k * red[0][0] * invM);    // subtracted constant
   }
 }
 
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const gode_bn_bwd_op a, int rows) {
   const int64_t n4 = a.M * a.C / 4;
-  const float* coef = a.work + (int64_t)rows * 2 * a.C;
+  const float* coef = a.work + (int64_t)rows * 4 * a.C;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const int c = (int)((i * 4) % a.C);
     f32x4 g = *reinterpret_cast<const f32x4*>(a.g + i * 4);
     const f32x4 y = *reinterpret_cast<const f32x4*>(a.y + i * 4);
     const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c), sh = *reinterpret_cast<const f32x4*>(a.shift + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + c);
     const f32x4 cA = *reinterpret_cast<const f32x4*>(coef + c), cB = *reinterpret_cast<const f32x4*>(coef + a.C + c),
                 cC = *reinterpret_cast<const f32x4*>(coef + 2 * a.C + c);
+    // g_y = k*g_z - k*dbeta/M - k*invstd*dgamma/M*(y - mean); (mean - y) is formed first so that a large |mean|
+    // does not cancel against a separately rounded constant
 #pragma unroll
-    for (int e = 0; e < 4; ++e) g[e] = cA[e] * gz_of(g[e], y[e], sc[e], sh[e], a.act) + cB[e] * y[e] + cC[e];
+    for (int e = 0; e < 4; ++e) g[e] = cA[e] * gz_of(g[e], y[e], sc[e], sh[e], a.act) + cB[e] * (mu[e] - y[e]) - cC[e];
     *reinterpret_cast<f32x4*>(a.g + i * 4) = g;
   }
 }
@@ -162,7 +168,7 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(float* g, const float* y, 
 
 extern "C" int64_t gode_bn_bwd_work_size(int64_t M, int32_t C) {
   const int64_t rows = (M + BNB_ROWS - 1) / BNB_ROWS;
-  return rows * 2 * C + 3 * (int64_t)C;
+  return rows * 4 * C + 3 * (int64_t)C;   // fp64 partials (2 floats each) + 3 coefficient vectors
 }
 
 static int ew_blocks(int64_t n) {

@@ -174,8 +174,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* work, fl
   const int Kt = Ci * taps;
   const int64_t total = (int64_t)Co * Kt;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int zz = 0; zz < splits; ++zz) s += work[(int64_t)zz * total + i];
+    double sd = 0.0;
+    for (int zz = 0; zz < splits; ++zz) sd += (double)work[(int64_t)zz * total + i];
+    const float s = (float)sd;
     int co = (int)(i / Kt);
     const int j = (int)(i - (int64_t)co * Kt);
     const int tap = j / Ci, ci = j - tap * Ci;

@@ -108,7 +108,8 @@ int gode_bn_finalize(const gode_bn_finalize_op* op, void* stream);
 /* backward of y -> BN -> act given g_a = dL/d(act output), all [M][C] channels-last:
  *   g_z = g_a * act'(scale*y+shift);  dbeta = sum g_z;  dgamma = sum g_z*xhat;
  *   g_y = gamma*invstd*(g_z - dbeta/M - xhat*dgamma/M)     written in place over g_a.
- * With mean==NULL the layer has no BN: g_y = g_a*act'(y).  work: >= 2*C*rows floats (rows = ceil(M/1024)).
+ * With mean==NULL the layer has no BN: g_y = g_a*act'(y).  work: >= gode_bn_bwd_work_size floats, 8-byte aligned
+ * (the two sums are accumulated in fp64).
  * accumulate!=0 adds into dgamma/dbeta. */
 typedef struct gode_bn_bwd_op {
   float* g; const float* y; int64_t M; int32_t C, act;

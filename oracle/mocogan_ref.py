@@ -69,16 +69,21 @@ class Generator(nn.Module):
         self.linear = _prenet(dim_z_motion)
         self.ode_method, self.ode_options = ode_method, ode_options
 
+    def _dtype(self):
+        """fp32 as the reference; a .double() copy of the module gives an fp64 yardstick fed by the SAME fp32 draws."""
+        return self.linear[0].weight.dtype
+
     # -- latent samplers; RNG call order is part of the contract (mocogan.py:249-269, mocogan_ode.py:133-148)
     def sample_z_content(self, n, video_len=None):
         T = video_len or self.video_length
         c = np.random.normal(0, 1, (n, self.dim_z_content)).astype(np.float32)
-        return torch.from_numpy(np.repeat(c, T, axis=0))
+        return torch.from_numpy(np.repeat(c, T, axis=0)).to(self._dtype())
 
     def sample_z_m(self, n, video_len=None):
         T = video_len or self.video_length
-        x = self.linear(torch.randn(n, self.dim_z_motion))
-        sol = ode_ref.odeint_adjoint(self.ode_fn, x, torch.linspace(0, 1, T).float(), method=self.ode_method,
+        x = self.linear(torch.randn(n, self.dim_z_motion).to(self._dtype()))
+        sol = ode_ref.odeint_adjoint(self.ode_fn, x, torch.linspace(0, 1, T).float().to(self._dtype()),
+                                     method=self.ode_method,
                                      options=self.ode_options)
         return sol.transpose(0, 1).reshape(-1, self.dim_z_motion)
 
