@@ -64,7 +64,8 @@ extern "C" int gode_bn_finalize(const gode_bn_finalize_op* op, void* stream) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // BatchNorm + activation backward
-#define BNB_ROWS 1024
+#define BNB_ROWS 256   // rows per reduction block
+#define BNB_CL 16      // float4 channel lanes per block (64 channels)
 
 __device__ __forceinline__ float gz_of(float g, float y, float sc, float sh, int act) {
   if (act == GODE_ACT_TANH_OUT) return g * (1.f - y * y);
@@ -75,13 +76,17 @@ __device__ __forceinline__ float gz_of(float g, float y, float sc, float sh, int
 // Both sums cancel heavily (signed gradients), and their error is fed back into every element of g_y, so they are
 // accumulated in fp64 end to end; the kernel stays HBM-bound (2 fp64 FMAs per 8 bytes read).
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const gode_bn_bwd_op a) {
+  // block = (row chunk blockIdx.x) x (channel group blockIdx.y); threads = CL float4 channel lanes x RL row lanes
   const int C4 = a.C >> 2, tid = threadIdx.x;
-  const int rl = 256 / C4;            // row lanes
-  const int cl = tid % C4, rlane = tid / C4;
+  const int CL = C4 < BNB_CL ? C4 : BNB_CL;
+  const int rl = 256 / CL;
+  const int cl = tid % CL, rlane = tid / CL;
+  const int c4 = blockIdx.y * CL + cl;
   __shared__ double red[2][256][4];
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-  if (rlane < rl) {
-    const int c = cl * 4;
+  const bool active = rlane < rl && c4 < C4;
+  if (active) {
+    const int c = c4 * 4;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c), sh = *reinterpret_cast<const f32x4*>(a.shift + c);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + c), is = *reinterpret_cast<const f32x4*>(a.invstd + c);
     const int64_t r0 = (int64_t)blockIdx.x * BNB_ROWS;
@@ -100,14 +105,14 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const gode_bn_bwd_op
 #pragma unroll
   for (int e = 0; e < 4; ++e) { red[0][tid][e] = s1[e]; red[1][tid][e] = s2[e]; }
   __syncthreads();
-  if (tid < C4) {
+  if (tid < CL && blockIdx.y * CL + tid < C4) {
     double t1[4] = {0, 0, 0, 0}, t2[4] = {0, 0, 0, 0};
     for (int j = 0; j < rl; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { t1[e] += red[0][j * C4 + tid][e]; t2[e] += red[1][j * C4 + tid][e]; }
-    double* dst = reinterpret_cast<double*>(a.work) + (int64_t)blockIdx.x * 2 * a.C;
+      for (int e = 0; e < 4; ++e) { t1[e] += red[0][j * CL + tid][e]; t2[e] += red[1][j * CL + tid][e]; }
+    double* dst = reinterpret_cast<double*>(a.work) + (int64_t)blockIdx.x * 2 * a.C + (blockIdx.y * CL + tid) * 4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { dst[tid * 4 + e] = t1[e]; dst[a.C + tid * 4 + e] = t2[e]; }
+    for (int e = 0; e < 4; ++e) { dst[e] = t1[e]; dst[a.C + e] = t2[e]; }
   }
 }
 
@@ -185,9 +190,11 @@ extern "C" int gode_bn_bwd(const gode_bn_bwd_op* op, void* stream) {
     GODE_LAUNCH_CHECK();
     return 0;
   }
-  if (op->C % 4 != 0 || op->C / 4 > 256 || !op->invstd || !op->scale || !op->shift || !op->work) return GODE_E_ARG;
+  if (op->C % 4 != 0 || !op->invstd || !op->scale || !op->shift || !op->work) return GODE_E_ARG;
+  const int C4 = op->C / 4, CL = C4 < BNB_CL ? C4 : BNB_CL;
+  if (256 % CL != 0) return GODE_E_SHAPE;
   const int rows = (int)((op->M + BNB_ROWS - 1) / BNB_ROWS);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rows), dim3(256), 0, st, *op);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rows, (C4 + CL - 1) / CL), dim3(256), 0, st, *op);
   GODE_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(op->C), dim3(256), 0, st, *op, rows);
   GODE_LAUNCH_CHECK();

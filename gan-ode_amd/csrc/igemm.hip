@@ -12,6 +12,7 @@
 // MFMA k-index trick: lane half h supplies k = 4h+j in step j, so one ds_read_b128 feeds four MFMAs.
 // Epilogue: raw (or tanh) store, 128-B coalesced along channels, plus deterministic per-column partial sums for
 // train-mode BatchNorm (no atomics).
+#include <stdlib.h>
 #include "common.h"
 #include "conv_geom.h"
 
@@ -231,6 +232,215 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const IgemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// FAST variant for the layers that carry the FLOPs: vector gather, Cg % 32 == 0 (so a 32-wide K slab never straddles
+// a tap and the tap decode is wave-uniform scalar work), K % 32 == 0.  The loop body is one basic block: loads are
+// unconditional (clamped address + mask), the BN/activation transform is branch-free, and the staging work of slab
+// s+1 is placed between the MFMA groups of slab s so that it issues in the shadow of the matrix pipe.
+template <int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs a) {
+  constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32, LDK = 36;
+  constexpr int RPP = NT / 8;
+  constexpr int AP = BM / RPP, BP = BN / RPP;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/loader mismatch");
+  constexpr int BUF = (BM + BN) * LDK;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BUF + BM * 5];
+  int* rowinfo = reinterpret_cast<int*>(smem + 2 * BUF);
+  int* outoff = rowinfo + BM * 4;
+
+  const PhaseGeom& P = a.G.ph[blockIdx.z];
+  const int mblk = blockIdx.x, nblk = blockIdx.y;
+  if (mblk * BM >= P.M) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int Cg = a.G.Cg, Ncols = a.G.Ncols;
+
+  for (int r = tid; r < BM; r += NT) {
+    const int m = mblk * BM + r;
+    int base = -1, bd = 0, bh = 0, bw = 0, oo = -1;
+    if (m < P.M) {
+      const int qw = m % P.Mw; int t = m / P.Mw;
+      const int qh = t % P.Mh; t /= P.Mh;
+      const int qd = t % P.Md; const int img = t / P.Md;
+      base = img * a.gsN;
+      bd = qd * a.G.Sd + P.Od; bh = qh * a.G.Sh + P.Oh; bw = qw * a.G.Sw + P.Ow;
+      oo = (((img * a.G.Xd + qd * a.G.OSd + P.Pd) * a.G.Xh + qh * a.G.OSh + P.Ph) * a.G.Xw + qw * a.G.OSw + P.Pw) *
+           Ncols;
+    }
+    rowinfo[r * 4 + 0] = base; rowinfo[r * 4 + 1] = bd; rowinfo[r * 4 + 2] = bh; rowinfo[r * 4 + 3] = bw;
+    outoff[r] = oo;
+  }
+  __syncthreads();
+
+  int rbase[AP], rbd[AP], rbh[AP], rbw[AP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    const int r = (tid >> 3) + RPP * i;
+    rbase[i] = rowinfo[r * 4 + 0]; rbd[i] = rowinfo[r * 4 + 1]; rbh[i] = rowinfo[r * 4 + 2]; rbw[i] = rowinfo[r * 4 + 3];
+  }
+  const int kchunk = (tid & 7) * 4;
+  const int J = a.G.J, Gd = a.G.Gd, Gh = a.G.Gh, Gw = a.G.Gw;
+  const int nslab = P.K >> 5;
+  // weight rows of this thread (clamped; rows >= Ncols are masked to zero)
+  const float* wrow[BP];
+  bool wok[BP];
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    const int n = nblk * BN + (tid >> 3) + RPP * i;
+    wok[i] = n < Ncols;
+    wrow[i] = a.w + P.w_off + (int64_t)(wok[i] ? n : Ncols - 1) * P.Kp + kchunk;
+  }
+  const bool xf = a.scale != nullptr;
+  const float neg = a.act == GODE_ACT_RELU ? 0.f : (a.act == GODE_ACT_LRELU ? 0.2f : 1.f);
+
+  // wave-uniform tap odometer for the slab being fetched
+  int c0 = 0, jd = 0, jh = 0, jw = 0;
+  f32x4 ra[AP], rb[BP], sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+  unsigned amask = 0;
+
+  auto fetch = [&](int slab) {
+    const int c = c0 + kchunk;
+    if (xf) { sc4 = *reinterpret_cast<const f32x4*>(a.scale + c); sh4 = *reinterpret_cast<const f32x4*>(a.shift + c); }
+    amask = 0;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int id = rbd[i] + J * jd, ih = rbh[i] + J * jh, iw = rbw[i] + J * jw;
+      const bool ok = rbase[i] >= 0 && (unsigned)id < (unsigned)Gd && (unsigned)ih < (unsigned)Gh && (unsigned)iw < (unsigned)Gw;
+      const int off = ok ? rbase[i] + id * a.gsD + ih * a.gsH + iw * a.gsW + c : 0;
+      ra[i] = *reinterpret_cast<const f32x4*>(a.src + off);
+      amask |= (ok ? 1u : 0u) << i;
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + slab * 32);
+    // advance the odometer (uniform)
+    c0 += 32;
+    if (c0 >= Cg) {
+      c0 = 0;
+      if (++jw == P.Tw) { jw = 0; if (++jh == P.Th) { jh = 0; ++jd; } }
+    }
+  };
+  auto stageA = [&](int buf) {
+    float* As = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      f32x4 v;
+      const bool ok = (amask >> i) & 1u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = ra[i][e] * sc4[e] + sh4[e];
+        t = t > 0.f ? t : t * neg;
+        v[e] = ok ? t : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(As + ((tid >> 3) + RPP * i) * LDK + kchunk) = v;
+    }
+  };
+  auto stageB = [&](int buf) {
+    float* Bs = smem + buf * BUF + BM * LDK;
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      f32x4 v = rb[i];
+      if (!wok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(Bs + ((tid >> 3) + RPP * i) * LDK + kchunk) = v;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
+  const float* Abase = smem + (wm * TM * 32 + frag_row) * LDK + frag_k;
+  const float* Bbase = smem + BM * LDK + (wn * TN * 32 + frag_row) * LDK + frag_k;
+  auto mma_group = [&](int buf, int kg) {
+    f32x4 af[TM], bf[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Abase + buf * BUF + i * 32 * LDK + kg * 8);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bbase + buf * BUF + j * 32 * LDK + kg * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+  };
+
+  fetch(0);
+  stageA(0);
+  stageB(0);
+  __syncthreads();
+  for (int s = 0; s + 1 < nslab; ++s) {
+    const int buf = s & 1;
+    fetch(s + 1);
+    mma_group(buf, 0);
+    mma_group(buf, 1);
+    stageA(buf ^ 1);
+    mma_group(buf, 2);
+    stageB(buf ^ 1);
+    mma_group(buf, 3);
+    __syncthreads();
+  }
+  {
+    const int buf = (nslab - 1) & 1;
+    mma_group(buf, 0); mma_group(buf, 1); mma_group(buf, 2); mma_group(buf, 3);
+    __syncthreads();
+  }
+
+  const int ccol = lane & 31, crow = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = nblk * BN + (wn * TN + j) * 32 + ccol;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + crow;
+        const int oo = outoff[row];
+        if (oo >= 0 && col < Ncols) {
+          float v = acc[i][j][r];
+          if (a.epilogue == GODE_EPI_TANH) v = tanhf(v);
+          a.out[oo + col] = v;
+        }
+      }
+    }
+
+  if (a.stats != nullptr) {
+    float* sred = smem;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; s1 += v; s2 += v * v; }
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lane < 32) {
+        const int c = (wn * TN + j) * 32 + lane;
+        sred[(wm * BN + c) * 2 + 0] = s1;
+        sred[(wm * BN + c) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += NT) {
+      const int col = nblk * BN + c;
+      if (col < Ncols) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { s1 += sred[(w * BN + c) * 2 + 0]; s2 += sred[(w * BN + c) * 2 + 1]; }
+        float* dst = a.stats + (int64_t)(P.row0 + mblk) * 2 * Ncols;
+        dst[col] = s1;
+        dst[Ncols + col] = s2;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 enum { TILE_128x128 = 1, TILE_128x64 = 2, TILE_128x32 = 3, TILE_64x64 = 4 };
 
 static int tile_bm(int tile) { return tile == TILE_64x64 ? 64 : 128; }
@@ -272,7 +482,10 @@ template <int WM, int WN, int TM, int TN>
 static int launch(const IgemmArgs& A, bool vec, int max_mblk, hipStream_t st) {
   constexpr int BN = WN * TN * 32;
   dim3 grid(max_mblk, gode_ceil_div(A.G.Ncols, BN), A.G.nphase), block(WM * WN * 64);
-  if (vec) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true>), grid, block, 0, st, A);
+  bool fast = vec && A.G.Cg % 32 == 0 && getenv("GODE_IGEMM_GENERIC") == nullptr;
+  for (int i = 0; i < A.G.nphase; ++i) fast = fast && A.G.ph[i].K >= 32 && A.G.ph[i].K % 32 == 0 && A.G.ph[i].Kp == A.G.ph[i].K;
+  if (fast) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN>), grid, block, 0, st, A);
+  else if (vec) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true>), grid, block, 0, st, A);
   else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false>), grid, block, 0, st, A);
   GODE_LAUNCH_CHECK();
   return 0;

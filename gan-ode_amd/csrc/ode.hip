@@ -23,7 +23,15 @@ __device__ __forceinline__ f32x4 matvec(const f32x4 w, const f32x4 x, f32x4 c) {
   for (int r = 0; r < 4; ++r) c = MFMA16(w[r], x[r], c);
   return c;
 }
-__device__ __forceinline__ f32x4 tanh4(const f32x4 u) { return f32x4{tanhf(u[0]), tanhf(u[1]), tanhf(u[2]), tanhf(u[3])}; }
+// tanh(x) = 1 - 2/(exp(2x)+1) on the hardware exp/rcp units (v_exp_f32, v_rcp_f32): absolute error ~1e-7, saturates
+// correctly at +-inf; libm's tanhf costs ~10x more instructions and dominated the solve (4 tanh per lane per RHS).
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float t = __expf(2.f * x);
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+}
+__device__ __forceinline__ f32x4 tanh4(const f32x4 u) {
+  return f32x4{fast_tanh(u[0]), fast_tanh(u[1]), fast_tanh(u[2]), fast_tanh(u[3])};
+}
 __device__ __forceinline__ f32x4 lrelu4(const f32x4 u) {
   f32x4 o;
 #pragma unroll

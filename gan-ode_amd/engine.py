@@ -152,14 +152,21 @@ class ConvStack:
         ptrs = self.param_ptrs()
         if ptrs != self._param_ptrs:
             self._fwd, self._bwd, self._param_ptrs = {}, None, ptrs
+            self._packed_f = self._packed_b = None
+
+    def weights_key(self):
+        """Changes whenever any conv weight may have changed: torch's in-place version counter (torch optimisers,
+        load_state_dict) plus the counter FusedAdam bumps (it updates through raw pointers)."""
+        return tuple((p.weight._version, getattr(p.weight, "_gode_ver", 0)) for p in self.params)
 
     # -- forward -------------------------------------------------------------------------------------------
     def _build_fwd(self, training: bool):
         ops = []
+        packs = []
         patch = {}
         for l, (s, p) in enumerate(zip(self.specs, self.params)):
-            ops.append(L.PackOp(g=s.geom, dir=s.fwd_dir, co_canon=0, w=dptr(p.weight), wpack=dptr(self.wpack_f[l]),
-                                co_perm=dptr(s.co_perm)))
+            packs.append(L.PackOp(g=s.geom, dir=s.fwd_dir, co_canon=0, w=dptr(p.weight), wpack=dptr(self.wpack_f[l]),
+                                  co_perm=dptr(s.co_perm)))
             sc, sh, act = self._in_xform(l)
             src = self.x_in if l == 0 else self.y[l - 1]
             op = L.IgemmOp(g=s.geom, dir=s.fwd_dir, act=act, epilogue=s.epilogue, tile=0, src=dptr(src),
@@ -180,6 +187,7 @@ class ConvStack:
                                           invstd=dptr(self.invstd[l]), scale=dptr(self.scale[l]),
                                           shift=dptr(self.shift[l]), momentum=self.momentum, eps=self.eps,
                                           training=1 if training else 0))
+        patch["packs"] = L.Program(packs)
         return L.Program(ops), patch
 
     def forward(self, training: bool, x: Optional[torch.Tensor] = None, x_strides=None, pre_ops_program=None):
@@ -198,6 +206,10 @@ class ConvStack:
                 first.gs[i] = int(x_strides[i])
             self._x_user, self._x_strides = x, tuple(int(v) for v in x_strides)
         st = stream_ptr()
+        wk = self.weights_key()
+        if getattr(self, "_packed_f", None) != wk:      # re-pack only when a weight changed since the last pack
+            patch["packs"].run(st)
+            self._packed_f = wk
         if pre_ops_program is not None:
             pre_ops_program.run(st)
         prog.run(st)
@@ -220,6 +232,7 @@ class ConvStack:
             self.g = [torch.empty(s.out_dims(), **f32) for s in self.specs]  # grad wrt raw/activated outputs
             self.g_in = torch.empty(self.specs[0].in_dims(), **f32)
         ops, patch = [], {"dw": [], "dgamma": [], "dbeta": []}
+        bpacks = []
         wg_work = 0
         bn_work = 0
         last = self.specs[-1]
@@ -250,8 +263,8 @@ class ConvStack:
             if l > 0 or need_input_grad:
                 if self.wpack_b[l] is None:
                     self.wpack_b[l] = torch.empty(lib.gode_pack_size(C.byref(s.geom), rev), **f32)
-                ops.append(L.PackOp(g=s.geom, dir=rev, co_canon=0, w=dptr(p.weight), wpack=dptr(self.wpack_b[l]),
-                                    co_perm=dptr(s.co_perm)))
+                bpacks.append(L.PackOp(g=s.geom, dir=rev, co_canon=0, w=dptr(p.weight), wpack=dptr(self.wpack_b[l]),
+                                       co_perm=dptr(s.co_perm)))
                 dst = self.g_in if l == 0 else self.g[l - 1]
                 ops.append(L.IgemmOp(g=s.geom, dir=rev, act=L.ACT_NONE, epilogue=L.EPI_RAW, tile=0, src=dptr(self.g[l]),
                                      wpack=dptr(self.wpack_b[l]), out=dptr(dst)))
@@ -276,6 +289,8 @@ class ConvStack:
         for b in patch.get("bnb", []):
             if b.mean:
                 b.work = self.bn_work.data_ptr()
+        patch["packs"] = L.Program(bpacks)
+        self._packed_b = None
         return L.Program(ops), patch
 
     def backward(self, gout: torch.Tensor, need_input_grad: bool, need_param_grad: bool = True):
@@ -287,6 +302,10 @@ class ConvStack:
             self._bwd = self._build_bwd(need_input_grad, need_param_grad)
             self._bwd_need_input = key
         prog, patch = self._bwd
+        wk = (self.weights_key(), self._bwd_need_input)
+        if getattr(self, "_packed_b", None) != wk:
+            patch["packs"].run(stream_ptr())
+            self._packed_b = wk
         self.g[-1].copy_(gout)
         if "tanh" in patch:
             patch["tanh"].y = self.out.data_ptr()

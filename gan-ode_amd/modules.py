@@ -89,6 +89,11 @@ class _GenPlan:
         self.ode_work = torch.empty(L.lib().gode_ode_bwd_work_size(n_traj), **f32)
         self._ode_ptrs = None
         self.busy = False
+        # pinned staging ring for the host-drawn noise: a pageable H2D copy would block the host until the stream
+        # drains (no host/GPU overlap between consecutive calls); slots are recycled behind an event
+        self._ring = [dict(x=torch.empty(n_traj, 16).pin_memory(), c=torch.empty(n_traj, 50).pin_memory(),
+                           s=torch.zeros(n_traj, dtype=torch.int32).pin_memory(), ev=None) for _ in range(4)]
+        self._ring_i = 0
 
     def _ode_params(self):
         g = self.gen
@@ -118,10 +123,20 @@ class _GenPlan:
 
     def forward(self, x_host, content_host, sel_host, training, keep):
         self._programs()
-        self.x.copy_(x_host, non_blocking=True)
-        self.content.copy_(content_host, non_blocking=True)
+        slot = self._ring[self._ring_i]
+        self._ring_i = (self._ring_i + 1) % len(self._ring)
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()
+        slot["x"].copy_(x_host)
+        slot["c"].copy_(content_host)
+        self.x.copy_(slot["x"], non_blocking=True)
+        self.content.copy_(slot["c"], non_blocking=True)
         if self.select:
-            self.sel.copy_(sel_host, non_blocking=True)
+            slot["s"].copy_(sel_host)
+            self.sel.copy_(slot["s"], non_blocking=True)
+        if slot["ev"] is None:
+            slot["ev"] = torch.cuda.Event()
+        slot["ev"].record()
         out = self.stack.forward(training, pre_ops_program=self.fwd_prog)
         self.busy = keep
         return out
@@ -291,7 +306,7 @@ class VideoGenerator(nn.Module):
         h = self._run(num_samples, T, False, x, content, None)            # [B*T, 1, H, W, C]
         H, W = h.size(2), h.size(3)
         h = h.view(num_samples, T, H, W, self.n_channels).permute(0, 4, 1, 2, 3)
-        labels = torch.from_numpy(np.zeros(num_samples)).to(h.device)
+        labels = torch.zeros(num_samples, dtype=torch.float64, device=h.device)   # np.zeros(B) -> .cuda() in the reference
         return h, labels
 
     def sample_images(self, num_samples):

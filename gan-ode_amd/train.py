@@ -78,6 +78,7 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
+                p._gode_ver = getattr(p, "_gode_ver", 0) + 1     # updated through a raw pointer: bump our own version
                 ops.append(L.AdamOp(p=p.data_ptr(), g=g.data_ptr(), m=st["exp_avg"].data_ptr(),
                                     v=st["exp_avg_sq"].data_ptr(), n=p.numel(), lr=group["lr"], beta1=b1, beta2=b2,
                                     eps=group["eps"], weight_decay=group["weight_decay"], gscale=gscale,

@@ -57,6 +57,24 @@ v32, l32 = run_oracle(o32)
 v64, l64 = run_oracle(o64)
 print(f"frames: hip-vs-f64 {rel(vid.detach().cpu(), v64):.2e}  cpu32-vs-f64 {rel(v32, v64):.2e}  hip-vs-cpu32 {rel(vid.detach().cpu(), v32):.2e}")
 print(f"loss:   hip {float(loss.detach()):.8f} cpu32 {l32:.8f} f64 {l64:.8f}")
+def chan_report(name, p, q, r):
+    """per-output-channel relative error: shows whether an L2 outlier is ONE channel (a ReLU kink flip upstream)."""
+    pg, qg, rg = p.grad.cpu().double(), q.grad.double(), r.grad.double()
+    pg, qg, rg = pg.reshape(pg.shape[0], -1), qg.reshape(qg.shape[0], -1), rg.reshape(rg.shape[0], -1)
+    if name.endswith("main.6.weight") or name.endswith("main.3.weight"):   # ConvTranspose: out channels on dim 1
+        shp = p.grad.shape
+        pg = p.grad.cpu().double().permute(1, 0, 2, 3).reshape(shp[1], -1)
+        qg = q.grad.double().permute(1, 0, 2, 3).reshape(shp[1], -1); rg = r.grad.double().permute(1, 0, 2, 3).reshape(shp[1], -1)
+    eh = ((pg - rg).norm(dim=1) / rg.norm()).tolist(); ec = ((qg - rg).norm(dim=1) / rg.norm()).tolist()
+    top = sorted(range(len(eh)), key=lambda i: -eh[i])[:4]
+    med = sorted(eh)[len(eh) // 2]
+    print(f"   {name}: hip top channels {[(i, f'{eh[i]:.1e}') for i in top]} median {med:.1e}; cpu32 max {max(ec):.1e}")
+
+
+for k in ("main.7.bias", "main.6.weight", "main.4.bias"):
+    P, Q, R = dict(gen.named_parameters()), dict(o32[0].named_parameters()), dict(o64[0].named_parameters())
+    chan_report("gen." + k, P[k], Q[k], R[k])
+
 for tag, m, a, b in (("gen", gen, o32[0], o64[0]), ("vid", dv, o32[1], o64[1]), ("img", di, o32[2], o64[2])):
     for (k, p), (_, q), (_, r) in zip(m.named_parameters(), a.named_parameters(), b.named_parameters()):
         if r.grad is None:

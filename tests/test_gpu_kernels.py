@@ -166,8 +166,8 @@ def test_wgrad_transform_on_either_side_and_accumulate():
         assert rel_err(dw.cpu() - base, wr.grad) < 2e-4
 
 
-def test_bn_finalize_and_backward():
-    M, Cc = 3000, 32
+@pytest.mark.parametrize("M,Cc", [(3000, 32), (5000, 128), (700, 512), (257, 8)])
+def test_bn_finalize_and_backward(M, Cc):
     gen = torch.Generator().manual_seed(9)
     y = torch.randn(M, Cc, generator=gen) * 2 + 1
     ga = torch.randn(M, Cc, generator=gen)
