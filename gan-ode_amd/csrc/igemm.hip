@@ -26,7 +26,29 @@ struct IgemmArgs {
   float* stats;
   int32_t gsN, gsD, gsH, gsW, gsC;
   int32_t act, epilogue;
+  int32_t MB, NB, xcd_mode;   // FAST kernel: 1-D grid of MB*NB*nphase workgroups, decoded XCD-aware (see igemm_block_id)
 };
+
+// Workgroups are dealt round-robin to the 8 XCDs in linear id order (id and id+8 share an XCD and its 4 MiB L2);
+// this is used for speed only.  xcd_mode 1 keeps all m-blocks of one (n-block, phase) "combo" on one XCD (its weight
+// panel stays L2-resident: layers whose packed weights exceed the L2), xcd_mode 2 keeps all combos of one m-block on
+// one XCD back to back (the gathered activation rows are fetched from HBM once: layers dominated by activation
+// traffic), 0 is the plain order.  Every mode is a bijection of [0, MB*NB*nphase).
+__device__ __forceinline__ void igemm_block_id(const IgemmArgs& a, int& mblk, int& nblk, int& phase) {
+  const int id = blockIdx.x, MB = a.MB, NC = a.NB * a.G.nphase;
+  int combo;
+  if (a.xcd_mode == 1) {
+    const int x = id & 7, j = id >> 3;
+    if ((NC & 7) == 0) { combo = x + 8 * (j / MB); mblk = j % MB; }
+    else { const int parts = 8 / NC; combo = x % NC; mblk = j * parts + x / NC; }
+  } else if (a.xcd_mode == 2) {
+    const int x = id & 7, j = id >> 3;
+    combo = j % NC; mblk = (j / NC) * 8 + x;
+  } else {
+    mblk = id % MB; combo = id / MB;
+  }
+  nblk = combo % a.NB; phase = combo / a.NB;
+}
 
 template <int WM, int WN, int TM, int TN, bool VEC>
 __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const IgemmArgs a) {
@@ -236,19 +258,24 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const IgemmArgs a) {
 // a tap and the tap decode is wave-uniform scalar work), K % 32 == 0.  The loop body is one basic block: loads are
 // unconditional (clamped address + mask), the BN/activation transform is branch-free, and the staging work of slab
 // s+1 is placed between the MFMA groups of slab s so that it issues in the shadow of the matrix pipe.
-template <int WM, int WN, int TM, int TN>
+// DB=true : two LDS buffers, one barrier per slab, staging interleaved with this wave's own MFMAs.
+// DB=false: one LDS buffer (half the LDS => twice the resident workgroups, 4 waves per SIMD), two barriers per slab;
+//           the staging of one workgroup is covered by the MFMAs of the three others on the SIMD.
+template <int WM, int WN, int TM, int TN, bool DB>
 __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs a) {
   constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32, LDK = 36;
   constexpr int RPP = NT / 8;
   constexpr int AP = BM / RPP, BP = BN / RPP;
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/loader mismatch");
   constexpr int BUF = (BM + BN) * LDK;
-  __shared__ __attribute__((aligned(16))) float smem[2 * BUF + BM * 5];
-  int* rowinfo = reinterpret_cast<int*>(smem + 2 * BUF);
+  constexpr int NBUF = DB ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * BUF + BM * 5];
+  int* rowinfo = reinterpret_cast<int*>(smem + NBUF * BUF);
   int* outoff = rowinfo + BM * 4;
 
-  const PhaseGeom& P = a.G.ph[blockIdx.z];
-  const int mblk = blockIdx.x, nblk = blockIdx.y;
+  int mblk, nblk, phase;
+  igemm_block_id(a, mblk, nblk, phase);
+  const PhaseGeom& P = a.G.ph[phase];
   if (mblk * BM >= P.M) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -370,23 +397,37 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
   };
 
   fetch(0);
-  stageA(0);
-  stageB(0);
-  __syncthreads();
-  for (int s = 0; s + 1 < nslab; ++s) {
-    const int buf = s & 1;
-    fetch(s + 1);
-    mma_group(buf, 0);
-    mma_group(buf, 1);
-    stageA(buf ^ 1);
-    mma_group(buf, 2);
-    stageB(buf ^ 1);
-    mma_group(buf, 3);
+  if (DB) {
+    stageA(0);
+    stageB(0);
     __syncthreads();
-  }
-  {
+    for (int s = 0; s + 1 < nslab; ++s) {
+      const int buf = s & 1;
+      fetch(s + 1);
+      mma_group(buf, 0);
+      mma_group(buf, 1);
+      stageA(buf ^ 1);
+      mma_group(buf, 2);
+      stageB(buf ^ 1);
+      mma_group(buf, 3);
+      __syncthreads();
+    }
     const int buf = (nslab - 1) & 1;
     mma_group(buf, 0); mma_group(buf, 1); mma_group(buf, 2); mma_group(buf, 3);
+    __syncthreads();
+  } else {
+    for (int s = 0; s + 1 < nslab; ++s) {
+      stageA(0);
+      stageB(0);
+      __syncthreads();
+      fetch(s + 1);
+      mma_group(0, 0); mma_group(0, 1); mma_group(0, 2); mma_group(0, 3);
+      __syncthreads();
+    }
+    stageA(0);
+    stageB(0);
+    __syncthreads();
+    mma_group(0, 0); mma_group(0, 1); mma_group(0, 2); mma_group(0, 3);
     __syncthreads();
   }
 
@@ -447,6 +488,7 @@ static int tile_bm(int tile) { return tile == TILE_64x64 ? 64 : 128; }
 static int tile_bn(int tile) { return tile == TILE_128x128 ? 128 : tile == TILE_128x32 ? 32 : 64; }
 
 static int pick_tile(const IgemmGeom& G, int requested) {
+  requested %= 10;   // +10: double-LDS-buffer variant of the same tile (tuning knob; default is single-buffer)
   if (requested >= TILE_128x128 && requested <= TILE_64x64) return requested;
   if (G.Ncols <= 32) return TILE_128x32;
   if (G.Ncols <= 64) return TILE_128x64;
@@ -479,12 +521,28 @@ extern "C" int gode_igemm_stats_rows(const gode_igemm_op* op) {
 }
 
 template <int WM, int WN, int TM, int TN>
-static int launch(const IgemmArgs& A, bool vec, int max_mblk, hipStream_t st) {
+static int launch(IgemmArgs& A, bool vec, int max_mblk, bool double_buf, hipStream_t st) {
   constexpr int BN = WN * TN * 32;
   dim3 grid(max_mblk, gode_ceil_div(A.G.Ncols, BN), A.G.nphase), block(WM * WN * 64);
   bool fast = vec && A.G.Cg % 32 == 0 && getenv("GODE_IGEMM_GENERIC") == nullptr;
   for (int i = 0; i < A.G.nphase; ++i) fast = fast && A.G.ph[i].K >= 32 && A.G.ph[i].K % 32 == 0 && A.G.ph[i].Kp == A.G.ph[i].K;
-  if (fast) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN>), grid, block, 0, st, A);
+  if (fast) {
+    const int MB = max_mblk, NB = (int)grid.y, NC = NB * A.G.nphase;
+    A.MB = MB; A.NB = NB; A.xcd_mode = 0;
+    static const char* xenv = getenv("GODE_IGEMM_XCD");
+    const int force = xenv ? atoi(xenv) : -1;
+    const int64_t wbytes = gode_pack_floats(A.G) * 4;
+    const bool ok1 = (NC % 8 == 0) || (NC < 8 && 8 % NC == 0 && MB % (8 / NC) == 0);
+    const bool ok2 = MB % 8 == 0;
+    int mode = (wbytes > (3 << 20) && ok1) ? 1 : (ok2 ? 2 : (ok1 ? 1 : 0));
+    if (force == 0) mode = 0;
+    if (force == 1 && ok1) mode = 1;
+    if (force == 2 && ok2) mode = 2;
+    A.xcd_mode = mode;
+    dim3 g1(MB * NC);
+    if (double_buf) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, true>), g1, block, 0, st, A);
+    else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false>), g1, block, 0, st, A);
+  }
   else if (vec) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true>), grid, block, 0, st, A);
   else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false>), grid, block, 0, st, A);
   GODE_LAUNCH_CHECK();
@@ -520,11 +578,12 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
                    (op->scale == nullptr || ((uintptr_t)op->scale % 16 == 0 && (uintptr_t)op->shift % 16 == 0));
   if (((uintptr_t)op->wpack % 16) != 0) return GODE_E_ARG;
   hipStream_t st = (hipStream_t)stream;
+  const bool sb = op->tile >= 10;   // request the double-buffered FAST variant
   switch (tile) {
-    case TILE_128x128: return launch<2, 2, 2, 2>(A, vec, max_mblk, st);
-    case TILE_128x64: return launch<2, 2, 2, 1>(A, vec, max_mblk, st);
-    case TILE_128x32: return launch<4, 1, 1, 1>(A, vec, max_mblk, st);
-    case TILE_64x64: return launch<2, 2, 1, 1>(A, vec, max_mblk, st);
+    case TILE_128x128: return launch<2, 2, 2, 2>(A, vec, max_mblk, sb, st);
+    case TILE_128x64: return launch<2, 2, 2, 1>(A, vec, max_mblk, sb, st);
+    case TILE_128x32: return launch<4, 1, 1, 1>(A, vec, max_mblk, sb, st);
+    case TILE_64x64: return launch<2, 2, 1, 1>(A, vec, max_mblk, sb, st);
   }
   return GODE_E_ARG;
 }
