@@ -26,3 +26,18 @@ __device__ __forceinline__ float gode_act_grad(float z, int act) {
 }
 
 static inline bool gode_strides_are_channels_last(const int64_t* s) { return s[0] == 0 && s[1] == 0 && s[2] == 0 && s[3] == 0 && s[4] == 0; }
+
+// Division by a run-time invariant (Granlund-Montgomery, branch-free, exact for all 32-bit n): the host builds the
+// magic once per launch, the kernels pay a v_mul_hi + 3 ALU ops instead of a ~30-instruction software divide.
+struct FastDiv { uint32_t mul, sh1, sh2, d; };
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f; f.d = d;
+  uint32_t l = 0; while ((1ull << l) < d) ++l;
+  f.mul = (uint32_t)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+  f.sh1 = l < 1 ? l : 1; f.sh2 = l > 0 ? l - 1 : 0;
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  const uint32_t t = __umulhi(f.mul, n);
+  return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}

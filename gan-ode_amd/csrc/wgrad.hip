@@ -7,6 +7,7 @@
 // The reduction is cut into `splits` slabs (grid.z), each writing its own [Co][taps*Ci] partial; a second kernel
 // sums the partials in fixed order and scatters into PyTorch's canonical W[co][ci][taps] layout (deterministic,
 // no float atomics).  The BN+activation of the producing layer is fused into whichever operand is an activation.
+#include <stdlib.h>
 #include "common.h"
 #include "conv_geom.h"
 
@@ -16,6 +17,7 @@ struct WgradArgs {
   int32_t xsN, xsD, xsH, xsW, xsC;
   int32_t act, xform_on_y;
   int32_t M, chunk, Kt, taps;
+  FastDiv dWo, dHo, dDo;
 };
 
 template <int WM, int WN, int TM, int TN, bool VECX, bool VECY>
@@ -169,6 +171,138 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// FAST path (vector loads on both operands): branch-free loop body (clamped loads + masks, magic-number position
+// decode), ONE LDS buffer (32 KB at 128x128 => four workgroups per CU cover each other's staging).
+template <int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(256) wgrad_fast_kernel(const WgradArgs a) {
+  constexpr int NT = 256, BI = WM * TM * 32, BJ = WN * TN * 32;
+  constexpr int YC = BI / 4, XC = BJ / 4, YR = NT / YC, XR = NT / XC, YP = 32 / YR, XP = 32 / XR;
+  static_assert(YP >= 1 && XP >= 1, "tile too narrow for the loader");
+  __shared__ __attribute__((aligned(16))) float smem[32 * (BI + BJ)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int jblk = blockIdx.x, iblk = blockIdx.y, z = blockIdx.z;
+  const gode_conv_geom& g = a.g;
+  const int m_begin = z * a.chunk;
+  const int m_end = m_begin + a.chunk < a.M ? m_begin + a.chunk : a.M;
+  const int nslab = m_end > m_begin ? (m_end - m_begin + 31) >> 5 : 0;
+
+  const int ych = tid % YC, yr0 = tid / YC, xch = tid % XC, xr0 = tid / XC;
+  const int co0 = iblk * BI + ych * 4, j0 = jblk * BJ + xch * 4;
+  const bool yok = co0 < g.Co, xok = j0 < a.Kt;
+  const int tap = xok ? j0 / g.Ci : 0;
+  const int xci = xok ? j0 - tap * g.Ci : 0;
+  const int xkw = tap % g.kw, xkh = (tap / g.kw) % g.kh, xkd = tap / (g.kw * g.kh);
+  f32x4 xsc = {1, 1, 1, 1}, xsh = {0, 0, 0, 0}, ysc = {1, 1, 1, 1}, ysh = {0, 0, 0, 0};
+  if (a.scale != nullptr) {
+    if (!a.xform_on_y && xok) { xsc = *reinterpret_cast<const f32x4*>(a.scale + xci); xsh = *reinterpret_cast<const f32x4*>(a.shift + xci); }
+    if (a.xform_on_y && yok) { ysc = *reinterpret_cast<const f32x4*>(a.scale + co0); ysh = *reinterpret_cast<const f32x4*>(a.shift + co0); }
+  }
+  const float nslope = a.act == GODE_ACT_RELU ? 0.f : (a.act == GODE_ACT_LRELU ? 0.2f : 1.f);
+  const float xneg = a.xform_on_y ? 1.f : nslope, yneg = a.xform_on_y ? nslope : 1.f;
+  const float* yptr = a.y + (yok ? co0 : 0);
+  const float* xptr = a.x + xci;
+
+  f32x4 ry[YP], rx[XP];
+  unsigned ymask = 0, xmask = 0;
+  auto fetch = [&](int slab) {
+    const int mb = m_begin + slab * 32;
+    ymask = 0; xmask = 0;
+#pragma unroll
+    for (int p = 0; p < YP; ++p) {
+      const int m = mb + yr0 + p * YR;
+      const bool ok = m < m_end && yok;
+      ry[p] = *reinterpret_cast<const f32x4*>(yptr + (int64_t)(ok ? m : m_begin) * g.Co);
+      ymask |= (ok ? 1u : 0u) << p;
+    }
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const uint32_t m = mb + xr0 + p * XR;
+      const uint32_t t1 = fdiv(m, a.dWo), qw = m - t1 * g.Wo;
+      const uint32_t t2 = fdiv(t1, a.dHo), qh = t1 - t2 * g.Ho;
+      const uint32_t img = fdiv(t2, a.dDo), qd = t2 - img * g.Do;
+      const int id = (int)qd * g.sd - g.pd + xkd, ih = (int)qh * g.sh - g.ph + xkh, iw = (int)qw * g.sw - g.pw + xkw;
+      const bool ok = (int)m < m_end && xok && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi &&
+                      (unsigned)iw < (unsigned)g.Wi;
+      const int off = ok ? (int)img * a.xsN + id * a.xsD + ih * a.xsH + iw * a.xsW : 0;
+      rx[p] = *reinterpret_cast<const f32x4*>(xptr + off);
+      xmask |= (ok ? 1u : 0u) << p;
+    }
+  };
+  auto stage = [&]() {
+    float* Ys = smem;
+    float* Xs = smem + 32 * BI;
+#pragma unroll
+    for (int p = 0; p < YP; ++p) {
+      f32x4 v;
+      const bool ok = (ymask >> p) & 1u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { float t = ry[p][e] * ysc[e] + ysh[e]; t = t > 0.f ? t : t * yneg; v[e] = ok ? t : 0.f; }
+      *reinterpret_cast<f32x4*>(Ys + (yr0 + p * YR) * BI + ych * 4) = v;
+    }
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      f32x4 v;
+      const bool ok = (xmask >> p) & 1u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { float t = rx[p][e] * xsc[e] + xsh[e]; t = t > 0.f ? t : t * xneg; v[e] = ok ? t : 0.f; }
+      *reinterpret_cast<f32x4*>(Xs + (xr0 + p * XR) * BJ + xch * 4) = v;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const float* Yr = smem + fh * BI + wm * TM * 32 + fr;
+  const float* Xr = smem + 32 * BI + fh * BJ + wn * TN * 32 + fr;
+  auto mma_slab = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = Yr[ks * 2 * BI + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Xr[ks * 2 * BJ + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  if (nslab > 0) {
+    fetch(0);
+    for (int s = 0; s + 1 < nslab; ++s) {
+      stage();
+      __syncthreads();
+      fetch(s + 1);
+      mma_slab();
+      __syncthreads();
+    }
+    stage();
+    __syncthreads();
+    mma_slab();
+  }
+
+  float* dst = a.work + (int64_t)z * g.Co * a.Kt;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = jblk * BJ + (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = iblk * BI + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < g.Co && col < a.Kt) dst[(int64_t)row * a.Kt + col] = acc[i][j][r];
+      }
+    }
+}
+
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* work, float* dw, int Co, int Ci, int taps,
                                                            int splits, const int32_t* co_perm, int accumulate) {
   const int Kt = Ci * taps;
@@ -213,7 +347,8 @@ template <int WM, int WN, int TM, int TN>
 static int wg_launch(const WgradArgs& A, bool vx, bool vy, int splits, hipStream_t st) {
   constexpr int BI = WM * TM * 32, BJ = WN * TN * 32;
   dim3 grid(gode_ceil_div(A.Kt, BJ), gode_ceil_div(A.g.Co, BI), splits), block(256);
-  if (vx && vy) hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, true, true>), grid, block, 0, st, A);
+  if (vx && vy && getenv("GODE_WGRAD_GENERIC") == nullptr) hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN>), grid, block, 0, st, A);
+  else if (vx && vy) hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, true, true>), grid, block, 0, st, A);
   else if (vx) hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, true, false>), grid, block, 0, st, A);
   else if (vy) hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, false, true>), grid, block, 0, st, A);
   else hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, false, false>), grid, block, 0, st, A);
@@ -242,6 +377,7 @@ extern "C" int gode_wgrad(const gode_wgrad_op* op, void* stream) {
   A.xsN = (int)xs[0]; A.xsD = (int)xs[1]; A.xsH = (int)xs[2]; A.xsW = (int)xs[3]; A.xsC = (int)xs[4];
   A.act = op->act; A.xform_on_y = op->xform_on_y;
   A.M = (int)M; A.taps = g.kd * g.kh * g.kw; A.Kt = A.taps * g.Ci;
+  A.dWo = make_fastdiv(g.Wo); A.dHo = make_fastdiv(g.Ho); A.dDo = make_fastdiv(g.Do);
   const int splits = wg_splits(op);
   A.chunk = (int)(((M + splits - 1) / splits + 31) / 32 * 32);
   const bool vx = xs[4] == 1 && g.Ci % 4 == 0 && xs[0] % 4 == 0 && xs[1] % 4 == 0 && xs[2] % 4 == 0 && xs[3] % 4 == 0 &&
