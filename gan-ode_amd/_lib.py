@@ -92,7 +92,7 @@ _STRUCTS = {0: ConvGeom, OP_IGEMM: IgemmOp, OP_WGRAD: WgradOp, OP_BN_FINALIZE: B
 EXPORTS = ["gode_igemm", "gode_igemm_stats_rows", "gode_pack_size", "gode_pack_weights", "gode_wgrad",
            "gode_wgrad_work_size", "gode_wgrad_auto_splits", "gode_bn_finalize", "gode_bn_bwd",
            "gode_bn_bwd_work_size", "gode_ode_fwd", "gode_ode_bwd", "gode_ode_bwd_work_size", "gode_bce_logits",
-           "gode_adam_l2", "gode_scale", "gode_run", "gode_version", "gode_sizeof"]
+           "gode_adam_l2", "gode_adam_multi", "gode_scale", "gode_run", "gode_version", "gode_sizeof"]
 
 _lib = None
 
@@ -129,6 +129,7 @@ def lib():
     L.gode_ode_bwd_work_size.argtypes = [i32]
     L.gode_ode_bwd_work_size.restype = i64
     L.gode_scale.argtypes = [ptr, ptr, i64, f32, C.c_int, ptr]
+    L.gode_adam_multi.argtypes = [ptr, i32, i64, f32, f32, f32, f32, f32, f32, i32, ptr]
     L.gode_run.argtypes = [ptr, ptr, i32, ptr]
     _lib = L
     return L

@@ -266,6 +266,30 @@ extern "C" int gode_adam_l2(const gode_adam_op* op, void* stream) {
   return 0;
 }
 
+__global__ void __launch_bounds__(256) adam_multi_kernel(const gode_adam_tensor* table, float b1, float b2, float eps,
+                                                         float wd, float gscale, float step_size, float bc2_sqrt) {
+  const gode_adam_tensor t = table[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < t.n; i += (int64_t)gridDim.x * 256) {
+    const float pi = t.p[i];
+    const float gi = t.g[i] * gscale + wd * pi;
+    const float mi = t.m[i] + (gi - t.m[i]) * (1.f - b1);
+    const float vi = t.v[i] * b2 + (1.f - b2) * gi * gi;
+    t.m[i] = mi; t.v[i] = vi;
+    t.p[i] = pi - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+}
+
+extern "C" int gode_adam_multi(const gode_adam_tensor* table, int32_t count, int64_t max_n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, float gscale, int32_t step, void* stream) {
+  if (!table || count <= 0 || max_n <= 0 || step < 1) return GODE_E_ARG;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  int bx = (int)((max_n + 255) / 256); if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(bx, count), dim3(256), 0, (hipStream_t)stream, table, beta1, beta2, eps,
+                     weight_decay, gscale, (float)((double)lr / bc1), (float)sqrt(bc2));
+  GODE_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ void __launch_bounds__(256) scale_kernel(float* out, const float* a, int64_t n, float alpha, int acc) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     out[i] = acc ? out[i] + a[i] * alpha : a[i] * alpha;

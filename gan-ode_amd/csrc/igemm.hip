@@ -482,6 +482,55 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Thin outputs (<= 4 columns) with a long K and few rows: the discriminators' last layers (Conv3d 512->1 k2,
+// Conv2d 256->1 k4; models/mocogan.py:88,158).  A 128x32 MFMA tile would run ~128 serial K slabs in a handful of
+// workgroups; here one wave owns one output position, its 64 lanes stride over K with float4 gathers and the
+// partial dot products are combined with wave shuffles.
+struct DotArgs { IgemmArgs a; FastDiv dCg; };
+
+__global__ void __launch_bounds__(256) conv_dot_kernel(const DotArgs d) {
+  const IgemmArgs& a = d.a;
+  const PhaseGeom& P = a.G.ph[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= P.M) return;
+  const int Cg = a.G.Cg, Ncols = a.G.Ncols;
+  const int qw = m % P.Mw; int t = m / P.Mw;
+  const int qh = t % P.Mh; t /= P.Mh;
+  const int qd = t % P.Md; const int img = t / P.Md;
+  const int base = img * a.gsN;
+  const int bd = qd * a.G.Sd + P.Od, bh = qh * a.G.Sh + P.Oh, bw = qw * a.G.Sw + P.Ow;
+  const float neg = a.act == GODE_ACT_RELU ? 0.f : (a.act == GODE_ACT_LRELU ? 0.2f : 1.f);
+  const bool xf = a.scale != nullptr;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* wp = a.w + P.w_off;
+  for (int k = lane * 4; k < P.K; k += 256) {
+    const int tap = (int)fdiv((uint32_t)k, d.dCg), c = k - tap * Cg;
+    const int jw = tap % P.Tw, t2 = tap / P.Tw, jh = t2 % P.Th, jd = t2 / P.Th;
+    const int id = bd + a.G.J * jd, ih = bh + a.G.J * jh, iw = bw + a.G.J * jw;
+    const bool ok = (unsigned)id < (unsigned)a.G.Gd && (unsigned)ih < (unsigned)a.G.Gh && (unsigned)iw < (unsigned)a.G.Gw;
+    if (ok) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(a.src + base + id * a.gsD + ih * a.gsH + iw * a.gsW + c);
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (xf) { sc = *reinterpret_cast<const f32x4*>(a.scale + c); sh = *reinterpret_cast<const f32x4*>(a.shift + c); }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { float u = v[e] * sc[e] + sh[e]; v[e] = u > 0.f ? u : u * neg; }
+      for (int n = 0; n < Ncols; ++n) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wp + (int64_t)n * P.Kp + k);
+        acc[n] += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+      }
+    }
+  }
+  const int oo = (((img * a.G.Xd + qd * a.G.OSd + P.Pd) * a.G.Xh + qh * a.G.OSh + P.Ph) * a.G.Xw + qw * a.G.OSw + P.Pw) * Ncols;
+  for (int n = 0; n < Ncols; ++n) {
+    float s = acc[n];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) a.out[oo + n] = a.epilogue == GODE_EPI_TANH ? tanhf(s) : s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 enum { TILE_128x128 = 1, TILE_128x64 = 2, TILE_128x32 = 3, TILE_64x64 = 4 };
 
 static int tile_bm(int tile) { return tile == TILE_64x64 ? 64 : 128; }
@@ -578,6 +627,20 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
                    (op->scale == nullptr || ((uintptr_t)op->scale % 16 == 0 && (uintptr_t)op->shift % 16 == 0));
   if (((uintptr_t)op->wpack % 16) != 0) return GODE_E_ARG;
   hipStream_t st = (hipStream_t)stream;
+  {
+    int maxM = 0, minK = 1 << 30; bool kp_ok = true;
+    for (int i = 0; i < G.nphase; ++i) {
+      if (G.ph[i].M > maxM) maxM = G.ph[i].M;
+      if (G.ph[i].K < minK) minK = G.ph[i].K;
+      kp_ok = kp_ok && G.ph[i].Kp == G.ph[i].K;
+    }
+    if (vec && kp_ok && G.Ncols <= 4 && op->stats == nullptr && maxM <= 16384 && minK >= 512 && op->tile == 0) {
+      DotArgs D; D.a = A; D.dCg = make_fastdiv((uint32_t)G.Cg);
+      hipLaunchKernelGGL(conv_dot_kernel, dim3(gode_ceil_div(maxM, 4), G.nphase), dim3(256), 0, st, D);
+      GODE_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   const bool sb = op->tile >= 10;   // request the double-buffered FAST variant
   switch (tile) {
     case TILE_128x128: return launch<2, 2, 2, 2>(A, vec, max_mblk, sb, st);

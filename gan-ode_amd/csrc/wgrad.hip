@@ -303,20 +303,37 @@ __global__ void __launch_bounds__(256) wgrad_fast_kernel(const WgradArgs a) {
     }
 }
 
+// sums the split-K slabs in fixed order (fp64 running sum) and scatters into the canonical layout; VEC4: four
+// consecutive (co, j) entries per thread with float4 slab reads (Kt % 4 == 0)
+template <bool VEC4>
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* work, float* dw, int Co, int Ci, int taps,
                                                            int splits, const int32_t* co_perm, int accumulate) {
   const int Kt = Ci * taps;
   const int64_t total = (int64_t)Co * Kt;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    double sd = 0.0;
-    for (int zz = 0; zz < splits; ++zz) sd += (double)work[(int64_t)zz * total + i];
-    const float s = (float)sd;
+  constexpr int V = VEC4 ? 4 : 1;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V; i < total; i += (int64_t)gridDim.x * 256 * V) {
+    double sd[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) sd[e] = 0.0;
+    for (int zz = 0; zz < splits; ++zz) {
+      if (VEC4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(work + (int64_t)zz * total + i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) sd[e] += (double)v[e];
+      } else {
+        sd[0] += (double)work[(int64_t)zz * total + i];
+      }
+    }
     int co = (int)(i / Kt);
-    const int j = (int)(i - (int64_t)co * Kt);
-    const int tap = j / Ci, ci = j - tap * Ci;
+    const int j0 = (int)(i - (int64_t)co * Kt);
     if (co_perm) { co = co_perm[co]; if (co < 0) continue; }
-    float* d = dw + ((int64_t)co * Ci + ci) * taps + tap;
-    *d = accumulate ? *d + s : s;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int j = j0 + e, tap = j / Ci, ci = j - tap * Ci;
+      float* dptr = dw + ((int64_t)co * Ci + ci) * taps + tap;
+      const float sv = (float)sd[e];
+      *dptr = accumulate ? *dptr + sv : sv;
+    }
   }
 }
 
@@ -328,7 +345,7 @@ extern "C" int gode_wgrad_auto_splits(const gode_conv_geom* g) {
   const int taps = g->kd * g->kh * g->kw, Kt = taps * g->Ci;
   const int64_t M = (int64_t)g->N * g->Do * g->Ho * g->Wo;
   const int64_t tiles = (int64_t)gode_ceil_div(g->Co, wg_bi(wg_tile(*g))) * gode_ceil_div(Kt, 128);
-  int64_t s = (768 + tiles - 1) / tiles;
+  int64_t s = (640 + tiles - 1) / tiles;
   const int64_t cap = (M + 63) / 64;
   if (s > cap) s = cap;
   if (s > 256) s = 256;
@@ -390,9 +407,12 @@ extern "C" int gode_wgrad(const gode_wgrad_op* op, void* stream) {
   else rc = wg_launch<2, 2, 2, 2>(A, vx, vy, splits, st);
   if (rc) return rc;
   const int64_t total = (int64_t)g.Co * A.Kt;
-  int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, op->work, op->dw, g.Co, g.Ci, A.taps, splits,
-                     op->co_perm, op->accumulate);
+  const bool v4 = A.Kt % 4 == 0 && (uintptr_t)op->work % 16 == 0;
+  int blocks = (int)((total / (v4 ? 4 : 1) + 255) / 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+  if (v4) hipLaunchKernelGGL((wgrad_reduce_kernel<true>), dim3(blocks), dim3(256), 0, st, op->work, op->dw, g.Co, g.Ci,
+                             A.taps, splits, op->co_perm, op->accumulate);
+  else hipLaunchKernelGGL((wgrad_reduce_kernel<false>), dim3(blocks), dim3(256), 0, st, op->work, op->dw, g.Co, g.Ci,
+                          A.taps, splits, op->co_perm, op->accumulate);
   GODE_LAUNCH_CHECK();
   return 0;
 }

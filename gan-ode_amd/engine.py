@@ -82,11 +82,14 @@ class ConvStack:
     per call with element strides (discriminators read the caller's video / image in place)."""
 
     def __init__(self, specs: Sequence[LayerSpec], params: Sequence[LayerParams], device, owns_input: bool,
-                 momentum=0.1, eps=1e-5):
+                 momentum=0.1, eps=1e-5, pack_cache: Optional[dict] = None):
         self.specs, self.params, self.device = list(specs), list(params), device
         self.nl = len(specs)
         self.momentum, self.eps = momentum, eps
         self.busy = False
+        # packed weight panels do not depend on the batch size: all plans of one module share them (and the record
+        # of which weight version each panel was packed from)
+        self.pack_cache = pack_cache if pack_cache is not None else {}
         lib = L.lib()
         f32 = dict(dtype=torch.float32, device=device)
         self.x_in = torch.zeros(specs[0].in_dims(), **f32) if owns_input else None
@@ -96,11 +99,11 @@ class ConvStack:
         self.wpack_f, self.wpack_b = [], [None] * self.nl
         self.stats, self.stat_rows = [], []
         self.mean, self.invstd, self.scale, self.shift = [], [], [], []
-        for s in specs:
+        for l, s in enumerate(specs):
             n = lib.gode_pack_size(C.byref(s.geom), s.fwd_dir)
             if n <= 0:
                 raise RuntimeError(f"bad geometry for pack ({n})")
-            self.wpack_f.append(torch.empty(n, **f32))
+            self.wpack_f.append(self._shared_pack(l, s.fwd_dir, n))
             C_out = s.out_dims()[4]
             if s.has_bn:
                 probe = L.IgemmOp(g=s.geom, dir=s.fwd_dir, tile=0)
@@ -120,6 +123,26 @@ class ConvStack:
         self._param_ptrs = None
 
     # -- helpers -------------------------------------------------------------------------------------------
+    def _shared_pack(self, l, direction, n):
+        key = ("buf", l, direction)
+        buf = self.pack_cache.get(key)
+        if buf is None or buf.numel() != n or buf.device != torch.device(self.device):
+            buf = self.pack_cache[key] = torch.empty(n, dtype=torch.float32, device=self.device)
+            self.pack_cache.pop(("ver", l, direction), None)
+        return buf
+
+    def _run_stale_packs(self, packs, st):
+        """packs: [(layer, dir, PackOp)].  Re-packs only panels whose weight changed since they were last packed."""
+        stale = []
+        for l, d, op in packs:
+            w = self.params[l].weight
+            ver = (w._version, getattr(w, "_gode_ver", 0), w.data_ptr())
+            if self.pack_cache.get(("ver", l, d)) != ver:
+                self.pack_cache[("ver", l, d)] = ver
+                stale.append(op)
+        if stale:
+            L.Program(stale).run(st)
+
     @staticmethod
     def _ncols(s: LayerSpec):
         g = s.geom
@@ -152,7 +175,6 @@ class ConvStack:
         ptrs = self.param_ptrs()
         if ptrs != self._param_ptrs:
             self._fwd, self._bwd, self._param_ptrs = {}, None, ptrs
-            self._packed_f = self._packed_b = None
 
     def weights_key(self):
         """Changes whenever any conv weight may have changed: torch's in-place version counter (torch optimisers,
@@ -165,8 +187,8 @@ class ConvStack:
         packs = []
         patch = {}
         for l, (s, p) in enumerate(zip(self.specs, self.params)):
-            packs.append(L.PackOp(g=s.geom, dir=s.fwd_dir, co_canon=0, w=dptr(p.weight), wpack=dptr(self.wpack_f[l]),
-                                  co_perm=dptr(s.co_perm)))
+            packs.append((l, s.fwd_dir, L.PackOp(g=s.geom, dir=s.fwd_dir, co_canon=0, w=dptr(p.weight),
+                                                 wpack=dptr(self.wpack_f[l]), co_perm=dptr(s.co_perm))))
             sc, sh, act = self._in_xform(l)
             src = self.x_in if l == 0 else self.y[l - 1]
             op = L.IgemmOp(g=s.geom, dir=s.fwd_dir, act=act, epilogue=s.epilogue, tile=0, src=dptr(src),
@@ -187,7 +209,7 @@ class ConvStack:
                                           invstd=dptr(self.invstd[l]), scale=dptr(self.scale[l]),
                                           shift=dptr(self.shift[l]), momentum=self.momentum, eps=self.eps,
                                           training=1 if training else 0))
-        patch["packs"] = L.Program(packs)
+        patch["packs"] = packs
         return L.Program(ops), patch
 
     def forward(self, training: bool, x: Optional[torch.Tensor] = None, x_strides=None, pre_ops_program=None):
@@ -206,10 +228,7 @@ class ConvStack:
                 first.gs[i] = int(x_strides[i])
             self._x_user, self._x_strides = x, tuple(int(v) for v in x_strides)
         st = stream_ptr()
-        wk = self.weights_key()
-        if getattr(self, "_packed_f", None) != wk:      # re-pack only when a weight changed since the last pack
-            patch["packs"].run(st)
-            self._packed_f = wk
+        self._run_stale_packs(patch["packs"], st)
         if pre_ops_program is not None:
             pre_ops_program.run(st)
         prog.run(st)
@@ -262,9 +281,9 @@ class ConvStack:
             # input gradient
             if l > 0 or need_input_grad:
                 if self.wpack_b[l] is None:
-                    self.wpack_b[l] = torch.empty(lib.gode_pack_size(C.byref(s.geom), rev), **f32)
-                bpacks.append(L.PackOp(g=s.geom, dir=rev, co_canon=0, w=dptr(p.weight), wpack=dptr(self.wpack_b[l]),
-                                       co_perm=dptr(s.co_perm)))
+                    self.wpack_b[l] = self._shared_pack(l, rev, lib.gode_pack_size(C.byref(s.geom), rev))
+                bpacks.append((l, rev, L.PackOp(g=s.geom, dir=rev, co_canon=0, w=dptr(p.weight),
+                                                wpack=dptr(self.wpack_b[l]), co_perm=dptr(s.co_perm))))
                 dst = self.g_in if l == 0 else self.g[l - 1]
                 ops.append(L.IgemmOp(g=s.geom, dir=rev, act=L.ACT_NONE, epilogue=L.EPI_RAW, tile=0, src=dptr(self.g[l]),
                                      wpack=dptr(self.wpack_b[l]), out=dptr(dst)))
@@ -289,8 +308,7 @@ class ConvStack:
         for b in patch.get("bnb", []):
             if b.mean:
                 b.work = self.bn_work.data_ptr()
-        patch["packs"] = L.Program(bpacks)
-        self._packed_b = None
+        patch["packs"] = bpacks
         return L.Program(ops), patch
 
     def backward(self, gout: torch.Tensor, need_input_grad: bool, need_param_grad: bool = True):
@@ -302,10 +320,7 @@ class ConvStack:
             self._bwd = self._build_bwd(need_input_grad, need_param_grad)
             self._bwd_need_input = key
         prog, patch = self._bwd
-        wk = (self.weights_key(), self._bwd_need_input)
-        if getattr(self, "_packed_b", None) != wk:
-            patch["packs"].run(stream_ptr())
-            self._packed_b = wk
+        self._run_stale_packs(patch["packs"], stream_ptr())
         self.g[-1].copy_(gout)
         if "tanh" in patch:
             patch["tanh"].y = self.out.data_ptr()

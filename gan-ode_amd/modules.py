@@ -36,6 +36,7 @@ class _Pool:
 
     def __init__(self):
         self.plans = {}
+        self.pack_cache = {}     # packed weight panels shared by every plan of the module
 
     def get(self, key, factory):
         lst = self.plans.setdefault(key, [])
@@ -53,6 +54,7 @@ class _Pool:
 
     def clear(self):
         self.plans.clear()
+        self.pack_cache.clear()
 
 
 # ==================================================================================================================
@@ -85,7 +87,8 @@ class _GenPlan:
         self.sel = torch.zeros(n_traj, dtype=torch.int32, device=dev) if select else None
         tt = torch.linspace(0, 1, T).float()            # models/mocogan_ode.py:143 -- fp32 grid built on the host
         self.dt = (tt[1:] - tt[:-1]).to(dev) if T > 1 else torch.zeros(1, **f32)
-        self.stack = ConvStack(gen._decoder_specs(self.rows), gen._decoder_params(), dev, owns_input=True)
+        self.stack = ConvStack(gen._decoder_specs(self.rows), gen._decoder_params(), dev, owns_input=True,
+                               pack_cache=gen._pool.pack_cache)
         self.ode_work = torch.empty(L.lib().gode_ode_bwd_work_size(n_traj), **f32)
         self._ode_ptrs = None
         self.busy = False
@@ -435,7 +438,8 @@ class _DiscBase(nn.Module):
             strides = (x.stride(0), 0, x.stride(2), x.stride(3), x.stride(1))
         key = tuple(x.shape)
         plan = self._pool.get(key, lambda: ConvStack(self._specs(x.shape), self._layer_params(),
-                                                     self.main[1].weight.device, owns_input=False))
+                                                     self.main[1].weight.device, owns_input=False,
+                                                     pack_cache=self._pool.pack_cache))
         params = []
         for p in self._layer_params():
             params.append(p.weight)

@@ -59,11 +59,14 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, grads: Optional[dict] = None, gscale: float = 1.0):
         """grads: optional {param: tensor} overriding .grad (views into an all-reduced bucket); gscale multiplies
-        every gradient (1/world_size for data parallelism)."""
+        every gradient (1/world_size for data parallelism).  All tensors of a param group are updated by ONE launch
+        (gode_adam_multi) driven by a small device table of pointers."""
         assert closure is None
-        ops = []
+        import numpy as np
+        lib = L.lib()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            rows, keep, step, max_n, dev = [], [], None, 0, None
             for p in group["params"]:
                 g = grads.get(p) if grads is not None else p.grad
                 if g is None:
@@ -78,14 +81,40 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
+                s_now = int(st["step"].item())
+                if step is None:
+                    step = s_now
+                if s_now != step:       # parameters on different step counts: fall back to one launch each
+                    L.run_one(L.AdamOp(p=p.data_ptr(), g=g.data_ptr(), m=st["exp_avg"].data_ptr(),
+                                       v=st["exp_avg_sq"].data_ptr(), n=p.numel(), lr=group["lr"], beta1=b1, beta2=b2,
+                                       eps=group["eps"], weight_decay=group["weight_decay"], gscale=gscale,
+                                       step=s_now), stream_ptr())
+                else:
+                    rows.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                 p.numel()))
+                    max_n = max(max_n, p.numel())
+                keep.append(g)
                 p._gode_ver = getattr(p, "_gode_ver", 0) + 1     # updated through a raw pointer: bump our own version
-                ops.append(L.AdamOp(p=p.data_ptr(), g=g.data_ptr(), m=st["exp_avg"].data_ptr(),
-                                    v=st["exp_avg_sq"].data_ptr(), n=p.numel(), lr=group["lr"], beta1=b1, beta2=b2,
-                                    eps=group["eps"], weight_decay=group["weight_decay"], gscale=gscale,
-                                    step=int(st["step"].item())))
-                ops[-1]._keep = g
-        if ops:
-            L.Program(ops).run(stream_ptr())
+                dev = p.device
+            if rows:
+                tbl = getattr(self, "_tables", None)
+                if tbl is None:
+                    tbl = self._tables = {}
+                n = len(rows)
+                ent = tbl.get(id(group))
+                if ent is None or ent["host"].shape[0] < n:
+                    ent = tbl[id(group)] = dict(host=torch.empty((n, 5), dtype=torch.int64).pin_memory(),
+                                                dev=torch.empty((n, 5), dtype=torch.int64, device=dev), ev=None)
+                if ent["ev"] is not None:
+                    ent["ev"].synchronize()
+                ent["host"][:n].copy_(torch.from_numpy(np.asarray(rows, dtype=np.int64)))
+                ent["dev"][:n].copy_(ent["host"][:n], non_blocking=True)
+                if ent["ev"] is None:
+                    ent["ev"] = torch.cuda.Event()
+                ent["ev"].record()
+                L.check(lib.gode_adam_multi(ent["dev"].data_ptr(), n, max_n, group["lr"], b1, b2, group["eps"],
+                                            group["weight_decay"], gscale, step, stream_ptr()), "gode_adam_multi")
+                self._keep = keep
         return None
 
 

@@ -162,6 +162,10 @@ typedef struct gode_adam_op {
   float lr, beta1, beta2, eps, weight_decay, gscale; int32_t step, pad_; /* step >= 1; gscale: 1/world for DP */
 } gode_adam_op;
 int gode_adam_l2(const gode_adam_op* op, void* stream);
+/* the same update on `count` tensors in ONE launch; `table` is a DEVICE array of {p, g, m, v, n} records */
+typedef struct gode_adam_tensor { float* p; const float* g; float* m; float* v; int64_t n; } gode_adam_tensor;
+int gode_adam_multi(const gode_adam_tensor* table, int32_t count, int64_t max_n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, float gscale, int32_t step, void* stream);
 
 /* out[i] = a[i]*alpha (+ out[i] if accumulate); small utility for gradient bucket handling */
 int gode_scale(float* out, const float* a, int64_t n, float alpha, int accumulate, void* stream);
