@@ -82,9 +82,15 @@ def _kernel_roofline(gen, reps=30):
         flop = 2.0 * macs * rows
         per_layer.append(dict(layer=name, ms=ms, gflop=flop / 1e9, tflops=flop / ms / 1e9))
     dom = max(per_layer[1:4], key=lambda d: d["ms"])
-    roof = {"bound": "mfma", "kernel": "igemm_kernel (fp32 MFMA 32x32x2), " + dom["layer"],
+    traffic = None   # HBM-side bytes per launch from the committed PMC passes (not collectable inside this process)
+    try:
+        pm = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["per_launch"]
+        traffic = pm[dom["layer"]]["traffic_bytes"]
+    except Exception:
+        pass
+    roof = {"bound": "mfma", "kernel": "igemm_fast_kernel (fp32 MFMA 32x32x2), " + dom["layer"],
             "achieved": round(dom["tflops"], 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(dom["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(dom["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "launch_ms": round(dom["ms"], 4), "algorithmic_gflop_per_launch": round(dom["gflop"], 2),
             "per_layer": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in per_layer]}
     return roof
@@ -122,7 +128,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("GODE_FORCE_DIST") == "1"   # (the latter: rehearse the RCCL path on 1 GPU)
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "

@@ -213,3 +213,43 @@ def test_full_width_mnist_batch32_against_oracle():
         again, _ = gen.sample_videos(B)
     # BN running stats do not enter train-mode outputs: same seed -> bit-identical frames (deterministic reductions)
     assert torch.equal(again, vid.detach())
+
+
+def test_full_width_ucf_against_oracle():
+    """BASELINE.json configs[3] shapes (UCF101: 3x64x64, ngf=ndf=64, ksize=4 video discriminator) at batch 4: frames,
+    logits, loss against the fp32 oracle at 1e-4; gradients bounded as in the MNIST full-width test."""
+    seed_all(17)
+    gen, dv, di = G.build_ucf()
+    o32 = M.build_ucf()
+    for m, o in zip((gen, dv, di), o32):
+        o.load_state_dict(m.state_dict())
+    gen.cuda(); dv.cuda(); di.cuda()
+    B = 4
+    seed_all(18)
+    vid, _ = gen.sample_videos(B)
+    img, _ = gen.sample_images(B)
+    pv, _ = dv(vid)
+    pi, _ = di(img)
+    loss = G.bce_with_logits_const(pv, 1.0) + G.bce_with_logits_const(pi, 1.0)
+    loss.backward()
+    og, ov, oi = o32
+    seed_all(18)
+    rvid, _ = og.sample_videos(B)
+    rimg, _ = og.sample_images(B)
+    rpv, _ = ov(rvid)
+    rpi, _ = oi(rimg)
+    bce = torch.nn.BCEWithLogitsLoss()
+    rloss = bce(rpv, torch.ones_like(rpv)) + bce(rpi, torch.ones_like(rpi))
+    rloss.backward()
+    assert vid.shape == (B, 3, 16, 64, 64) and pv.shape == (B,) and pi.shape == (B, 4, 4)
+    assert not vid.is_contiguous()          # a permuted view of the channels-last buffer, like the reference's view
+    assert rel_err(vid.detach().cpu(), rvid.detach()) < TOL
+    assert rel_err(img.detach().cpu(), rimg.detach()) < TOL
+    assert rel_err(pv.detach().cpu(), rpv.detach()) < TOL and rel_err(pi.detach().cpu(), rpi.detach()) < TOL
+    assert abs(float(loss.detach()) - float(rloss.detach())) / abs(float(rloss.detach())) < TOL
+    for m, a in zip((gen, dv, di), o32):
+        for (k, p), (_, q) in zip(m.named_parameters(), a.named_parameters()):
+            if q.grad is None:
+                assert p.grad is None, k
+            else:
+                assert robust_rel(p.grad.cpu(), q.grad) < 1e-2 and rel_l2(p.grad.cpu(), q.grad) < 1e-1, k
