@@ -26,7 +26,8 @@ class ConvGeom(C.Structure):
 
 class IgemmOp(C.Structure):
     _fields_ = [("g", ConvGeom), ("dir", i32), ("act", i32), ("epilogue", i32), ("tile", i32), ("src", ptr),
-                ("wpack", ptr), ("out", ptr), ("scale", ptr), ("shift", ptr), ("stats", ptr), ("gs", i64 * 5)]
+                ("wpack", ptr), ("out", ptr), ("scale", ptr), ("shift", ptr), ("stats", ptr), ("gs", i64 * 5),
+                ("work", ptr)]
     KIND = OP_IGEMM
 
 
@@ -89,7 +90,7 @@ class PackOp(C.Structure):
 _STRUCTS = {0: ConvGeom, OP_IGEMM: IgemmOp, OP_WGRAD: WgradOp, OP_BN_FINALIZE: BnFinalizeOp, OP_BN_BWD: BnBwdOp,
             OP_ODE_FWD: OdeFwdOp, OP_ODE_BWD: OdeBwdOp, OP_BCE: BceOp, OP_ADAM: AdamOp, OP_PACK: PackOp}
 
-EXPORTS = ["gode_igemm", "gode_igemm_stats_rows", "gode_pack_size", "gode_pack_weights", "gode_wgrad",
+EXPORTS = ["gode_igemm", "gode_igemm_stats_rows", "gode_igemm_work_size", "gode_pack_size", "gode_pack_weights", "gode_wgrad",
            "gode_wgrad_work_size", "gode_wgrad_auto_splits", "gode_bn_finalize", "gode_bn_bwd",
            "gode_bn_bwd_work_size", "gode_ode_fwd", "gode_ode_bwd", "gode_ode_bwd_work_size", "gode_bce_logits",
            "gode_adam_l2", "gode_adam_multi", "gode_scale", "gode_run", "gode_version", "gode_sizeof"]
@@ -118,6 +119,8 @@ def lib():
         getattr(L, name).argtypes = [ptr, ptr]
         getattr(L, name).restype = C.c_int
     L.gode_igemm_stats_rows.argtypes = [ptr]
+    L.gode_igemm_work_size.argtypes = [ptr]
+    L.gode_igemm_work_size.restype = i64
     L.gode_pack_size.argtypes = [ptr, C.c_int]
     L.gode_pack_size.restype = i64
     L.gode_pack_weights.argtypes = [ptr, C.c_int, ptr, ptr, ptr, i32, ptr]

@@ -27,6 +27,9 @@ struct IgemmArgs {
   int32_t gsN, gsD, gsH, gsW, gsC;
   int32_t act, epilogue;
   int32_t MB, NB, xcd_mode;   // FAST kernel: 1-D grid of MB*NB*nphase workgroups, decoded XCD-aware (see igemm_block_id)
+  int32_t ksplit, slabs_per_split;   // split-K: grid is ksplit copies of the above; partial tiles go to work
+  float* work;
+  int32_t out_numel;
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs in linear id order (id and id+8 share an XCD and its 4 MiB L2);
@@ -34,8 +37,10 @@ struct IgemmArgs {
 // panel stays L2-resident: layers whose packed weights exceed the L2), xcd_mode 2 keeps all combos of one m-block on
 // one XCD back to back (the gathered activation rows are fetched from HBM once: layers dominated by activation
 // traffic), 0 is the plain order.  Every mode is a bijection of [0, MB*NB*nphase).
-__device__ __forceinline__ void igemm_block_id(const IgemmArgs& a, int& mblk, int& nblk, int& phase) {
-  const int id = blockIdx.x, MB = a.MB, NC = a.NB * a.G.nphase;
+__device__ __forceinline__ void igemm_block_id(const IgemmArgs& a, int& mblk, int& nblk, int& phase, int& split) {
+  const int MB = a.MB, NC = a.NB * a.G.nphase;
+  split = blockIdx.x / (MB * NC);
+  const int id = blockIdx.x - split * (MB * NC);
   int combo;
   if (a.xcd_mode == 1) {
     const int x = id & 7, j = id >> 3;
@@ -273,8 +278,8 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
   int* rowinfo = reinterpret_cast<int*>(smem + NBUF * BUF);
   int* outoff = rowinfo + BM * 4;
 
-  int mblk, nblk, phase;
-  igemm_block_id(a, mblk, nblk, phase);
+  int mblk, nblk, phase, split;
+  igemm_block_id(a, mblk, nblk, phase, split);
   const PhaseGeom& P = a.G.ph[phase];
   if (mblk * BM >= P.M) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -306,7 +311,10 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
   }
   const int kchunk = (tid & 7) * 4;
   const int J = a.G.J, Gd = a.G.Gd, Gh = a.G.Gh, Gw = a.G.Gw;
-  const int nslab = P.K >> 5;
+  const int nslab_all = P.K >> 5;
+  const int s_begin = split * a.slabs_per_split;
+  const int s_last = a.ksplit > 1 ? (s_begin + a.slabs_per_split < nslab_all ? s_begin + a.slabs_per_split : nslab_all) : nslab_all;
+  const int nslab = s_last > s_begin ? s_last - s_begin : 0;   // slabs of THIS workgroup
   // weight rows of this thread (clamped; rows >= Ncols are masked to zero)
   const float* wrow[BP];
   bool wok[BP];
@@ -314,13 +322,18 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
   for (int i = 0; i < BP; ++i) {
     const int n = nblk * BN + (tid >> 3) + RPP * i;
     wok[i] = n < Ncols;
-    wrow[i] = a.w + P.w_off + (int64_t)(wok[i] ? n : Ncols - 1) * P.Kp + kchunk;
+    wrow[i] = a.w + P.w_off + (int64_t)(wok[i] ? n : Ncols - 1) * P.Kp + kchunk + s_begin * 32;
   }
   const bool xf = a.scale != nullptr;
   const float neg = a.act == GODE_ACT_RELU ? 0.f : (a.act == GODE_ACT_LRELU ? 0.2f : 1.f);
 
-  // wave-uniform tap odometer for the slab being fetched
-  int c0 = 0, jd = 0, jh = 0, jw = 0;
+  // wave-uniform tap odometer for the slab being fetched (starts at this workgroup's first slab)
+  int c0, jd, jh, jw;
+  {
+    const int k0 = s_begin * 32, tap0 = k0 / Cg;
+    c0 = k0 - tap0 * Cg;
+    jw = tap0 % P.Tw; const int t2 = tap0 / P.Tw; jh = t2 % P.Th; jd = t2 / P.Th;
+  }
   f32x4 ra[AP], rb[BP], sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
   unsigned amask = 0;
 
@@ -396,6 +409,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
   };
 
+  if (nslab > 0) {
   fetch(0);
   if (DB) {
     stageA(0);
@@ -430,8 +444,11 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
     mma_group(0, 0); mma_group(0, 1); mma_group(0, 2); mma_group(0, 3);
     __syncthreads();
   }
+  }
 
   const int ccol = lane & 31, crow = 4 * (lane >> 5);
+  const bool partial = a.ksplit > 1;
+  float* const dst = partial ? a.work + (int64_t)split * a.out_numel : a.out;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -443,13 +460,13 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
         const int oo = outoff[row];
         if (oo >= 0 && col < Ncols) {
           float v = acc[i][j][r];
-          if (a.epilogue == GODE_EPI_TANH) v = tanhf(v);
-          a.out[oo + col] = v;
+          if (!partial && a.epilogue == GODE_EPI_TANH) v = tanhf(v);
+          dst[oo + col] = v;
         }
       }
     }
 
-  if (a.stats != nullptr) {
+  if (a.stats != nullptr && !partial) {
     float* sred = smem;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -477,6 +494,33 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
         dst[col] = s1;
         dst[Ncols + col] = s2;
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+#define SPLITK_ROWS 16
+// split-K finish: sums the partial tiles in fixed order, applies the epilogue and produces the BatchNorm partial sums
+// (one stats row per SPLITK_ROWS output positions, so that even a 512-position output spreads over 32 workgroups).  Threads own columns, so every sum has a fixed order.
+__global__ void __launch_bounds__(256) igemm_splitk_reduce_kernel(const float* work, float* out, float* stats, int positions,
+                                                                  int Ncols, int ksplit, int epilogue) {
+  const int row0 = blockIdx.x * SPLITK_ROWS;
+  const int nrows = positions - row0 < SPLITK_ROWS ? positions - row0 : SPLITK_ROWS;
+  const int64_t numel = (int64_t)positions * Ncols;
+  for (int col = threadIdx.x; col < Ncols; col += 256) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+    for (int r = 0; r < nrows; ++r) {
+      const int64_t i = (int64_t)(row0 + r) * Ncols + col;
+      float v = 0.f;
+#pragma unroll 4
+      for (int sp = 0; sp < ksplit; ++sp) v += work[sp * numel + i];
+      s1 += v; s2 += v * v;
+      out[i] = epilogue == GODE_EPI_TANH ? tanhf(v) : v;
+    }
+    if (stats) {
+      stats[(int64_t)blockIdx.x * 2 * Ncols + col] = s1;
+      stats[(int64_t)blockIdx.x * 2 * Ncols + Ncols + col] = s2;
     }
   }
 }
@@ -546,10 +590,62 @@ static int pick_tile(const IgemmGeom& G, int requested) {
   return blocks >= 192 ? TILE_128x128 : TILE_64x64;
 }
 
-static int prepare(const gode_igemm_op* op, IgemmArgs* A, int* tile, int* max_mblk, int* rows) {
+// split-K plan: purely a function of the geometry (so gode_igemm_stats_rows / gode_igemm_work_size agree with the
+// launch).  Used when the FAST kernel applies and the natural grid would leave most of the 256 CUs idle.
+struct SplitPlan { int ksplit, slabs_per_split, positions; };
+
+static bool fast_geometry(const IgemmGeom& G) {
+  bool ok = G.Cg % 32 == 0;
+  for (int i = 0; i < G.nphase; ++i) ok = ok && G.ph[i].K >= 32 && G.ph[i].K % 32 == 0 && G.ph[i].Kp == G.ph[i].K;
+  return ok;
+}
+
+static bool strides_allow_vec(const gode_igemm_op* op, const IgemmGeom& G) {
+  if (gode_strides_are_channels_last(op->gs)) return G.Cg % 4 == 0;
+  return op->gs[4] == 1 && G.Cg % 4 == 0 && op->gs[0] % 4 == 0 && op->gs[1] % 4 == 0 && op->gs[2] % 4 == 0 &&
+         op->gs[3] % 4 == 0;
+}
+
+static SplitPlan plan_split(const gode_igemm_op* op, const IgemmGeom& G, int tile) {
+  const gode_conv_geom& g = op->g;
+  SplitPlan sp; sp.ksplit = 1; sp.slabs_per_split = 0; sp.positions = g.N * G.Xd * G.Xh * G.Xw;
+  if (!fast_geometry(G) || G.Ncols <= 4 || !strides_allow_vec(op, G) || op->tile >= 10) return sp;
+  const int bm = tile == 4 ? 64 : 128, bn = tile == 1 ? 128 : (tile == 3 ? 32 : 64);
+  int64_t blocks = 0; int max_slabs = 0, min_slabs = 1 << 30;
+  for (int i = 0; i < G.nphase; ++i) {
+    blocks += (int64_t)gode_ceil_div(G.ph[i].M, bm) * gode_ceil_div(G.Ncols, bn);
+    const int ns = G.ph[i].K >> 5;
+    if (ns > max_slabs) max_slabs = ns;
+    if (ns < min_slabs) min_slabs = ns;
+  }
+  if (blocks >= 64 || min_slabs < 8) return sp;   // only grids that would leave >3/4 of the CUs idle
+  int k = (int)((512 + blocks - 1) / blocks);
+  if (k > min_slabs / 4) k = min_slabs / 4;
+  if (k > 32) k = 32;
+  if (k < 2) return sp;
+  sp.slabs_per_split = gode_ceil_div(max_slabs, k);
+  sp.ksplit = gode_ceil_div(max_slabs, sp.slabs_per_split);
+  return sp;
+}
+
+static int pick_tile_split_aware(const gode_conv_geom& g, const IgemmGeom& G, int requested) {
+  const int t = pick_tile(G, requested);
+  if (requested % 10 != 0 || !fast_geometry(G) || G.Ncols <= 4) return t;
+  // with split-K available a starved grid is better served by the big tile (unless there are very few rows)
+  int maxM = 0;
+  for (int i = 0; i < G.nphase; ++i) if (G.ph[i].M > maxM) maxM = G.ph[i].M;
+  int64_t blocks = 0;
+  for (int i = 0; i < G.nphase; ++i) blocks += (int64_t)gode_ceil_div(G.ph[i].M, 128) * gode_ceil_div(G.Ncols, 128);
+  if (t == TILE_64x64 && maxM > 64 && blocks < 64) return G.Ncols <= 64 ? TILE_128x64 : TILE_128x128;
+  (void)g;
+  return t;
+}
+
+static int prepare(const gode_igemm_op* op, IgemmArgs* A, int* tile, int* max_mblk, int* rows, SplitPlan* sp) {
   int rc = gode_build_igemm_geom(op->g, op->dir, &A->G);
   if (rc) return rc;
-  *tile = pick_tile(A->G, op->tile);
+  *tile = pick_tile_split_aware(op->g, A->G, op->tile);
+  *sp = plan_split(op, A->G, *tile);
   const int bm = tile_bm(*tile);
   int r0 = 0, mx = 0;
   for (int i = 0; i < A->G.nphase; ++i) {
@@ -559,22 +655,30 @@ static int prepare(const gode_igemm_op* op, IgemmArgs* A, int* tile, int* max_mb
     if (mb > mx) mx = mb;
   }
   *max_mblk = mx;
-  *rows = r0;
+  *rows = sp->ksplit > 1 ? gode_ceil_div(sp->positions, SPLITK_ROWS) : r0;
   return 0;
 }
 
 extern "C" int gode_igemm_stats_rows(const gode_igemm_op* op) {
-  IgemmArgs A; int tile, mx, rows;
-  int rc = prepare(op, &A, &tile, &mx, &rows);
+  IgemmArgs A; int tile, mx, rows; SplitPlan sp;
+  int rc = prepare(op, &A, &tile, &mx, &rows, &sp);
   return rc ? rc : rows;
 }
 
+extern "C" int64_t gode_igemm_work_size(const gode_igemm_op* op) {
+  IgemmArgs A; int tile, mx, rows; SplitPlan sp;
+  int rc = prepare(op, &A, &tile, &mx, &rows, &sp);
+  if (rc) return rc;
+  return sp.ksplit > 1 ? (int64_t)sp.ksplit * sp.positions * A.G.Ncols : 0;
+}
+
 template <int WM, int WN, int TM, int TN>
-static int launch(IgemmArgs& A, bool vec, int max_mblk, bool double_buf, hipStream_t st) {
+static int launch(IgemmArgs& A, bool vec, int max_mblk, bool double_buf, const SplitPlan& sp, hipStream_t st) {
   constexpr int BN = WN * TN * 32;
   dim3 grid(max_mblk, gode_ceil_div(A.G.Ncols, BN), A.G.nphase), block(WM * WN * 64);
-  bool fast = vec && A.G.Cg % 32 == 0 && getenv("GODE_IGEMM_GENERIC") == nullptr;
-  for (int i = 0; i < A.G.nphase; ++i) fast = fast && A.G.ph[i].K >= 32 && A.G.ph[i].K % 32 == 0 && A.G.ph[i].Kp == A.G.ph[i].K;
+  bool fast = vec && fast_geometry(A.G) && (sp.ksplit > 1 || getenv("GODE_IGEMM_GENERIC") == nullptr);
+  if (sp.ksplit > 1 && (!fast || A.work == nullptr)) return GODE_E_ARG;   // the plan needs the FAST path + workspace
+  A.ksplit = sp.ksplit; A.slabs_per_split = sp.slabs_per_split;
   if (fast) {
     const int MB = max_mblk, NB = (int)grid.y, NC = NB * A.G.nphase;
     A.MB = MB; A.NB = NB; A.xcd_mode = 0;
@@ -588,9 +692,14 @@ static int launch(IgemmArgs& A, bool vec, int max_mblk, bool double_buf, hipStre
     if (force == 1 && ok1) mode = 1;
     if (force == 2 && ok2) mode = 2;
     A.xcd_mode = mode;
-    dim3 g1(MB * NC);
+    dim3 g1(MB * NC * sp.ksplit);
     if (double_buf) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, true>), g1, block, 0, st, A);
     else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false>), g1, block, 0, st, A);
+    if (sp.ksplit > 1) {
+      GODE_LAUNCH_CHECK();
+      hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(gode_ceil_div(sp.positions, SPLITK_ROWS)), dim3(256), 0, st, A.work, A.out,
+                         A.stats, sp.positions, A.G.Ncols, sp.ksplit, A.epilogue);
+    }
   }
   else if (vec) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true>), grid, block, 0, st, A);
   else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false>), grid, block, 0, st, A);
@@ -602,7 +711,8 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
   if (!op || !op->src || !op->wpack || !op->out) return GODE_E_ARG;
   IgemmArgs A;
   int tile, max_mblk, rows;
-  int rc = prepare(op, &A, &tile, &max_mblk, &rows);
+  SplitPlan sp;
+  int rc = prepare(op, &A, &tile, &max_mblk, &rows, &sp);
   if (rc) return rc;
   if (max_mblk == 0) return 0;
   const IgemmGeom& G = A.G;
@@ -621,6 +731,7 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
   A.src = op->src; A.w = op->wpack; A.out = op->out; A.scale = op->scale; A.shift = op->shift; A.stats = op->stats;
   A.gsN = (int)gs[0]; A.gsD = (int)gs[1]; A.gsH = (int)gs[2]; A.gsW = (int)gs[3]; A.gsC = (int)gs[4];
   A.act = op->act; A.epilogue = op->epilogue;
+  A.work = op->work; A.out_numel = (int32_t)outn; A.ksplit = 1; A.slabs_per_split = 0; A.MB = 0; A.NB = 0; A.xcd_mode = 0;
   if ((op->scale == nullptr) != (op->shift == nullptr)) return GODE_E_ARG;
   const bool vec = gs[4] == 1 && (G.Cg % 4) == 0 && (gs[0] % 4) == 0 && (gs[1] % 4) == 0 && (gs[2] % 4) == 0 &&
                    (gs[3] % 4) == 0 && ((uintptr_t)op->src % 16) == 0 &&
@@ -643,10 +754,10 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
   }
   const bool sb = op->tile >= 10;   // request the double-buffered FAST variant
   switch (tile) {
-    case TILE_128x128: return launch<2, 2, 2, 2>(A, vec, max_mblk, sb, st);
-    case TILE_128x64: return launch<2, 2, 2, 1>(A, vec, max_mblk, sb, st);
-    case TILE_128x32: return launch<4, 1, 1, 1>(A, vec, max_mblk, sb, st);
-    case TILE_64x64: return launch<2, 2, 1, 1>(A, vec, max_mblk, sb, st);
+    case TILE_128x128: return launch<2, 2, 2, 2>(A, vec, max_mblk, sb, sp, st);
+    case TILE_128x64: return launch<2, 2, 2, 1>(A, vec, max_mblk, sb, sp, st);
+    case TILE_128x32: return launch<4, 1, 1, 1>(A, vec, max_mblk, sb, sp, st);
+    case TILE_64x64: return launch<2, 2, 1, 1>(A, vec, max_mblk, sb, sp, st);
   }
   return GODE_E_ARG;
 }

@@ -116,6 +116,7 @@ class ConvStack:
             else:
                 self.stat_rows.append(0); self.stats.append(None)
                 self.mean.append(None); self.invstd.append(None); self.scale.append(None); self.shift.append(None)
+        self._ig_work = None    # split-K workspace shared by the plan's igemm ops (they run back to back)
         self._fwd = {}          # training flag -> Program
         self._bwd = None
         self._bwd_need_input = None
@@ -130,6 +131,20 @@ class ConvStack:
             buf = self.pack_cache[key] = torch.empty(n, dtype=torch.float32, device=self.device)
             self.pack_cache.pop(("ver", l, direction), None)
         return buf
+
+    def _attach_work(self, igemm_ops):
+        """Give every igemm op of a program the shared split-K workspace (sized for the largest request)."""
+        lib = L.lib()
+        need = max([lib.gode_igemm_work_size(C.byref(op)) for op in igemm_ops] + [0])
+        if need > 0:
+            if self._ig_work is None or self._ig_work.numel() < need:
+                self._ig_work = torch.empty(need, dtype=torch.float32, device=self.device)
+                for prog_ops in getattr(self, "_all_igemm", []):
+                    for op in prog_ops:
+                        op.work = self._ig_work.data_ptr()
+            for op in igemm_ops:
+                op.work = self._ig_work.data_ptr()
+        self.__dict__.setdefault("_all_igemm", []).append(list(igemm_ops))
 
     def _run_stale_packs(self, packs, st):
         """packs: [(layer, dir, PackOp)].  Re-packs only panels whose weight changed since they were last packed."""
@@ -175,6 +190,7 @@ class ConvStack:
         ptrs = self.param_ptrs()
         if ptrs != self._param_ptrs:
             self._fwd, self._bwd, self._param_ptrs = {}, None, ptrs
+            self._all_igemm = []
 
     def weights_key(self):
         """Changes whenever any conv weight may have changed: torch's in-place version counter (torch optimisers,
@@ -210,6 +226,7 @@ class ConvStack:
                                           shift=dptr(self.shift[l]), momentum=self.momentum, eps=self.eps,
                                           training=1 if training else 0))
         patch["packs"] = packs
+        self._attach_work([op for op in ops if isinstance(op, L.IgemmOp)])
         return L.Program(ops), patch
 
     def forward(self, training: bool, x: Optional[torch.Tensor] = None, x_strides=None, pre_ops_program=None):
@@ -309,6 +326,7 @@ class ConvStack:
             if b.mean:
                 b.work = self.bn_work.data_ptr()
         patch["packs"] = bpacks
+        self._attach_work([op for op in ops if isinstance(op, L.IgemmOp)])
         return L.Program(ops), patch
 
     def backward(self, gout: torch.Tensor, need_input_grad: bool, need_param_grad: bool = True):

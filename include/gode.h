@@ -59,8 +59,11 @@ typedef struct gode_igemm_op {
   const float* shift;
   float* stats;
   int64_t gs[5];
+  float* work; /* nullable; >= gode_igemm_work_size floats enables split-K for launches that would not fill the GPU */
 } gode_igemm_op;
 int gode_igemm(const gode_igemm_op* op, void* stream);
+/* floats of workspace the op can use for split-K (0: it never splits).  Deterministic from the op's geometry. */
+int64_t gode_igemm_work_size(const gode_igemm_op* op);
 /* number of partial-stats rows gode_igemm writes for this op (host-side, no GPU work) */
 int gode_igemm_stats_rows(const gode_igemm_op* op);
 /* floats needed for the packed weights of (geom, dir) */

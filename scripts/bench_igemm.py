@@ -18,7 +18,7 @@ ap.add_argument("--only", default="")
 ap.add_argument("--tiles", default="0")
 a = ap.parse_args()
 lib = L.lib()
-R = 512
+R = int(os.environ.get("GODE_BENCH_ROWS", "512"))
 
 
 def timeit(op):
@@ -48,6 +48,8 @@ def run_igemm(name, g, direction, flop, xform=True, tiles=(0,)):
         op = L.IgemmOp(g=g, dir=direction, act=L.ACT_RELU, epilogue=L.EPI_RAW, tile=tile, src=src.data_ptr(),
                        wpack=wp.data_ptr(), out=out.data_ptr(), scale=sc.data_ptr() if xform else None,
                        shift=sh.data_ptr() if xform else None)
+        work = torch.empty(max(lib.gode_igemm_work_size(C.byref(op)), 1), device="cuda")
+        op.work = work.data_ptr()
         rows = lib.gode_igemm_stats_rows(C.byref(op))
         stats = torch.empty(rows * 2 * out_dims[-1] * 16 + 16, device="cuda")
         op.stats = stats.data_ptr()

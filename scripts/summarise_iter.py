@@ -7,14 +7,14 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 groups = []
 prev_adam = False
 for i, r in enumerate(rows):
-    is_adam = "adam_kernel" in r["Kernel_Name"]
+    is_adam = "adam_" in r["Kernel_Name"]
     if is_adam and not prev_adam:
         groups.append(i)
     prev_adam = is_adam
 # last iteration: from after the end of adam group[-6] to end of group[-1]
 def end_of(gi):
     j = groups[gi]
-    while j < len(rows) and "adam_kernel" in rows[j]["Kernel_Name"]:
+    while j < len(rows) and "adam_" in rows[j]["Kernel_Name"]:
         j += 1
     return j
 i0, i1 = end_of(-6), end_of(-1)

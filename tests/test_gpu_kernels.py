@@ -54,6 +54,9 @@ def igemm(g, direction, src, w, out_dims, scale=None, shift=None, act=L.ACT_NONE
     if strides is not None:
         for i in range(5):
             op.gs[i] = strides[i]
+    wsz = lib.gode_igemm_work_size(C.byref(op))
+    work = torch.empty(max(wsz, 1), device="cuda")
+    op.work = work.data_ptr()
     stats = None
     if want_stats:
         rows = lib.gode_igemm_stats_rows(C.byref(op))
@@ -104,7 +107,7 @@ def test_igemm_fprop_dgrad_wgrad(case):
     xd = dev(x)
     st = (xd.stride(0), xd.stride(2), xd.stride(3), xd.stride(4), xd.stride(1))
     out2, _ = igemm(g, L.FPROP, xd, dev(w), (N, *yo, Co), strides=st)
-    assert rel_err(out2.cpu(), out.cpu()) < 1e-6
+    assert rel_err(out2.cpu(), out.cpu()) < 1e-5     # generic strided path vs FAST (possibly split-K) path: summation order differs
     # DGRAD
     gx, _ = igemm(g, L.DGRAD, dev(cl(gy)), dev(w), (N, *xi, Ci))
     assert rel_err(uncl(gx).cpu(), xr.grad) < TOL

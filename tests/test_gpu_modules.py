@@ -55,7 +55,13 @@ def test_generator_against_reference_fixture(tag, mnist, n_vid, n_img):
         if ref.size == 0:
             assert p.grad is None, k
         else:
-            assert rel_err(p.grad.cpu(), ref) < GTOL, k
+            # median-based error: robust against a single (Leaky)ReLU/BatchNorm kink flipping between two fp32
+            # evaluations (see test_full_width_mnist_batch32_against_oracle); max-norm only as a sanity bound
+            # In these tiny nets a BatchNorm channel averages only 256..4096 elements, so ONE flipped kink is a
+            # 1/256 = 4e-3 relative change of that channel's gradient and shifts everything upstream by about as
+            # much; 5e-3 bounds one flip, a wrong formula is O(0.1..1).
+            assert robust_rel(p.grad.cpu(), ref) < 5e-3, (k, robust_rel(p.grad.cpu(), ref), rel_err(p.grad.cpu(), ref))
+            assert rel_err(p.grad.cpu(), ref) < 5e-2, (k, rel_err(p.grad.cpu(), ref))
     for k, v in gen.state_dict().items():
         if "running_" in k:
             assert rel_err(v.cpu(), g[f"w_after/{k}"]) < TOL, k
