@@ -303,6 +303,82 @@ __global__ void __launch_bounds__(256) wgrad_fast_kernel(const WgradArgs a) {
     }
 }
 
+// THIN path: very few weight columns (Kt = taps*Ci <= 16: first discriminator layers with 1/3 input channels, the
+// generator's 64->1 output layer).  An MFMA tile would be >90% padding; instead every thread keeps 4 output channels
+// x Kt taps in registers, strides over positions, and the workgroup combines its position lanes through LDS.  Output:
+// one [Co][Kt] slab per workgroup in the same layout the split-K reduce consumes.
+#define THIN_MAXKT 16
+__global__ void __launch_bounds__(256) wgrad_thin_kernel(const WgradArgs a, int chunk_thin) {
+  const gode_conv_geom& g = a.g;
+  const int C4 = g.Co >> 2;                 // float4 channel lanes (Co % 4 == 0, C4 <= 256)
+  const int CL = C4 < 64 ? C4 : 64;
+  const int ML = 256 / CL;                  // position lanes
+  const int tid = threadIdx.x, cl = tid % CL, ml = tid / CL;
+  const int Kt = a.Kt;
+  __shared__ float red[256][4];
+  const float nslope = a.act == GODE_ACT_RELU ? 0.f : (a.act == GODE_ACT_LRELU ? 0.2f : 1.f);
+  const float xneg = a.xform_on_y ? 1.f : nslope, yneg = a.xform_on_y ? nslope : 1.f;
+  const int m0 = blockIdx.x * chunk_thin;
+  const int m1 = m0 + chunk_thin < a.M ? m0 + chunk_thin : a.M;
+  for (int cg = 0; cg < C4; cg += CL) {     // channel groups (one pass unless Co > 256)
+    const int c4 = cg + cl;
+    const bool cok = ml < ML && c4 < C4;
+    f32x4 acc[THIN_MAXKT];
+#pragma unroll
+    for (int j = 0; j < THIN_MAXKT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 ysc = {1, 1, 1, 1}, ysh = {0, 0, 0, 0};
+    if (cok && a.scale && a.xform_on_y) { ysc = *reinterpret_cast<const f32x4*>(a.scale + c4 * 4); ysh = *reinterpret_cast<const f32x4*>(a.shift + c4 * 4); }
+    if (cok) {
+      for (int m = m0 + ml; m < m1; m += ML) {
+        f32x4 yv = *reinterpret_cast<const f32x4*>(a.y + (int64_t)m * g.Co + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float t = yv[e] * ysc[e] + ysh[e]; yv[e] = t > 0.f ? t : t * yneg; }
+        const uint32_t t1 = fdiv((uint32_t)m, a.dWo), qw = m - t1 * g.Wo;
+        const uint32_t t2 = fdiv(t1, a.dHo), qh = t1 - t2 * g.Ho;
+        const uint32_t img = fdiv(t2, a.dDo), qd = t2 - img * g.Do;
+        const int bd = (int)qd * g.sd - g.pd, bh = (int)qh * g.sh - g.ph, bw = (int)qw * g.sw - g.pw;
+        int ci = 0, kw = 0, kh = 0, kd = 0;
+#pragma unroll
+        for (int j = 0; j < THIN_MAXKT; ++j) {
+          if (j < Kt) {
+            const int id = bd + kd, ih = bh + kh, iw = bw + kw;
+            float xv = 0.f;
+            if ((unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi) {
+              xv = a.x[(int)img * a.xsN + id * a.xsD + ih * a.xsH + iw * a.xsW + ci * a.xsC];
+              if (!a.xform_on_y) {
+                const float sc = a.scale ? a.scale[ci] : 1.f, sh = a.scale ? a.shift[ci] : 0.f;
+                xv = xv * sc + sh; xv = xv > 0.f ? xv : xv * xneg;
+              }
+            }
+            acc[j] += yv * xv;
+            if (++ci == g.Ci) { ci = 0; if (++kw == g.kw) { kw = 0; if (++kh == g.kh) { kh = 0; ++kd; } } }
+          }
+        }
+      }
+    }
+    // combine the position lanes: one tap at a time through LDS (fixed order)
+    float* dst = a.work + (int64_t)blockIdx.x * g.Co * Kt;
+#pragma unroll
+    for (int j = 0; j < THIN_MAXKT; ++j) {
+      if (j < Kt) {            // wave-uniform: every thread of the workgroup takes the same branch
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[tid][e] = cok ? acc[j][e] : 0.f;
+        __syncthreads();
+        if (tid < CL && cg + tid < C4) {
+          f32x4 s = {0.f, 0.f, 0.f, 0.f};
+          for (int q = 0; q < ML; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += red[q * CL + tid][e];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[(int64_t)((cg + tid) * 4 + e) * Kt + j] = s[e];
+        }
+      }
+    }
+  }
+}
+
+
 // sums the split-K slabs in fixed order (fp64 running sum) and scatters into the canonical layout; VEC4: four
 // consecutive (co, j) entries per thread with float4 slab reads (Kt % 4 == 0)
 template <bool VEC4>
@@ -315,6 +391,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* work, fl
     double sd[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) sd[e] = 0.0;
+#pragma unroll 8
     for (int zz = 0; zz < splits; ++zz) {
       if (VEC4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(work + (int64_t)zz * total + i);
@@ -353,7 +430,19 @@ extern "C" int gode_wgrad_auto_splits(const gode_conv_geom* g) {
   return (int)s;
 }
 
-static int wg_splits(const gode_wgrad_op* op) { return op->splits > 0 ? op->splits : gode_wgrad_auto_splits(&op->g); }
+static bool wg_thin(const gode_conv_geom& g) {
+  const int Kt = g.kd * g.kh * g.kw * g.Ci;
+  return Kt <= THIN_MAXKT && g.Co % 4 == 0 && (256 % ((g.Co / 4) < 64 ? (g.Co / 4) : 64)) == 0;
+}
+static int wg_thin_blocks(const gode_conv_geom& g) {
+  const int64_t M = (int64_t)g.N * g.Do * g.Ho * g.Wo;
+  int64_t b = (M + 1023) / 1024;
+  return (int)(b > 256 ? 256 : (b < 1 ? 1 : b));
+}
+static int wg_splits(const gode_wgrad_op* op) {
+  if (op->splits <= 0 && wg_thin(op->g)) return wg_thin_blocks(op->g);
+  return op->splits > 0 ? op->splits : gode_wgrad_auto_splits(&op->g);
+}
 
 extern "C" int64_t gode_wgrad_work_size(const gode_wgrad_op* op) {
   const int taps = op->g.kd * op->g.kh * op->g.kw;
@@ -402,7 +491,12 @@ extern "C" int gode_wgrad(const gode_wgrad_op* op, void* stream) {
   const bool vy = g.Co % 4 == 0 && (uintptr_t)op->y % 16 == 0;
   hipStream_t st = (hipStream_t)stream;
   const int t = wg_tile(g);
-  if (t == 0) rc = wg_launch<1, 4, 1, 1>(A, vx, vy, splits, st);
+  if (op->splits <= 0 && wg_thin(g) && vy) {
+    const int chunk_thin = (int)((M + splits - 1) / splits);
+    hipLaunchKernelGGL(wgrad_thin_kernel, dim3(splits), dim3(256), 0, st, A, chunk_thin);
+    GODE_LAUNCH_CHECK();
+    rc = 0;
+  } else if (t == 0) rc = wg_launch<1, 4, 1, 1>(A, vx, vy, splits, st);
   else if (t == 1) rc = wg_launch<2, 2, 1, 2>(A, vx, vy, splits, st);
   else rc = wg_launch<2, 2, 2, 2>(A, vx, vy, splits, st);
   if (rc) return rc;
