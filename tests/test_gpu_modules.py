@@ -259,3 +259,57 @@ def test_full_width_ucf_against_oracle():
                 assert p.grad is None, k
             else:
                 assert robust_rel(p.grad.cpu(), q.grad) < 1e-2 and rel_l2(p.grad.cpu(), q.grad) < 1e-1, k
+
+
+def test_unchanged_driver_surface_with_stock_adam_and_bce():
+    """The reference driver's own import lines and loop body (mnist_moco_ode.py:5-6,86-89,113-163) with torch's
+    stock Adam and BCEWithLogitsLoss on the drop-in classes, against the oracle driven the same way."""
+    from models.mocogan import VideoDiscriminator, PatchImageDiscriminator
+    from models.mocogan_ode import VideoGeneratorMNISTODE as VideoGeneratorMNIST
+    import torch.nn as nn
+    g = golden("train_mnist_tiny.npz")
+    s = int(g["seed"])
+    disVid, disImg = VideoDiscriminator(1, ksize=2, ndf=8), PatchImageDiscriminator(1, ndf=8)
+    gen = VideoGeneratorMNIST(1, 50, 0, 16, 16, ngf=8)
+    for m, p in ((gen, "gen"), (disVid, "vid"), (disImg, "img")):
+        load_sd(m, g, f"w0/{p}")
+    disVid.cuda(); disImg.cuda(); gen.cuda()
+    mk = lambda m: torch.optim.Adam(m.parameters(), lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)  # noqa: E731
+    disVidOpt, disImgOpt, genOpt = mk(disVid), mk(disImg), mk(gen)
+    loss = nn.BCEWithLogitsLoss()
+    batch_size = 8
+    for it in range(2):
+        seed_all(s + 1 + it)
+        for i in range(2):
+            disImgOpt.zero_grad()
+            real = _f32(g[f"real_img/{it}/{i}"]).cuda()
+            pr, _ = disImg(real)
+            with torch.no_grad():
+                fake, _ = gen.sample_images(batch_size)
+            pf, _ = disImg(fake)
+            dis_img_loss = loss(pr, torch.ones_like(pr)) + loss(pf, torch.zeros_like(pf))
+            dis_img_loss.backward()
+            disImgOpt.step()
+            disVidOpt.zero_grad()
+            real = _f32(g[f"real_vid/{it}/{i}"]).cuda().transpose(1, 2)
+            pr, _ = disVid(real)
+            with torch.no_grad():
+                fake, _ = gen.sample_videos(batch_size)
+            pf, _ = disVid(fake)
+            dis_vid_loss = loss(pr, torch.ones_like(pr)) + loss(pf, torch.zeros_like(pf))
+            dis_vid_loss.backward()
+            disVidOpt.step()
+        genOpt.zero_grad()
+        fakeVid, _ = gen.sample_videos(batch_size)
+        fakeImg, _ = gen.sample_images(batch_size)
+        pf_vid, _ = disVid(fakeVid)
+        pf_img, _ = disImg(fakeImg)
+        gen_loss = loss(pf_vid, torch.ones_like(pf_vid)) + loss(pf_img, torch.ones_like(pf_img))
+        gen_loss.backward()
+        genOpt.step()
+        got = [dis_img_loss.item(), dis_vid_loss.item(), gen_loss.item()]
+        assert np.allclose(got, g["losses"][it], rtol=2e-4, atol=0), (got, g["losses"][it])
+    # the discriminators' .grad were filled by the generator step too, as in the reference (no freezing here)
+    assert all(p.grad is not None for p in disVid.parameters())
+    sd = gen.state_dict()
+    assert float((sd["main.0.weight"].cpu() - torch.from_numpy(g["w1/gen/main.0.weight"])).abs().median()) < 2e-6

@@ -143,3 +143,32 @@ def test_grad_bucket_all_reduce_two_ranks_gloo():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_rot_mnist_reader_and_device_streams(tmp_path):
+    """Input side: the .mat contract of dataset/mnist_rotation.py and the shuffled drop_last
+    streams, on a synthetic file of the right shape."""
+    from scipy.io import savemat
+    from gan_ode_amd.data import MNISTRotationImage, MNISTRotationVideo, RotMnistOnDevice
+    rng = np.random.RandomState(0)
+    X = rng.rand(40, 16, 784).astype(np.float32)
+    savemat(tmp_path / "rot.mat", {"X": X, "Y": np.arange(40)[:, None]})
+    vid = MNISTRotationVideo(str(tmp_path / "rot.mat"), N=30)
+    img = MNISTRotationImage(str(tmp_path / "rot.mat"), N=30)
+    assert len(vid) == 30 and vid[3][0].shape == (16, 1, 28, 28) and int(vid[3][1]) == 3
+    assert np.array_equal(vid[3][0].numpy().reshape(16, 784), X[3])
+    np.random.seed(5)
+    f = np.random.randint(0, 16)
+    np.random.seed(5)
+    assert np.array_equal(img[7][0].numpy().reshape(784), X[7, f])
+    with pytest.raises(FileExistsError):
+        MNISTRotationVideo(str(tmp_path / "missing.mat"))
+    dev = RotMnistOnDevice(vid.X, device="cpu", seed=1)
+    vs, ims = dev.videos(8), dev.images(8)
+    seen = []
+    for _ in range(3):                       # 30 clips, batch 8, drop_last -> 3 batches per epoch
+        v = next(vs)
+        assert v.shape == (8, 16, 1, 28, 28)
+        seen += [int(np.where((X[:30] == v[i].numpy().reshape(16, 784)).all(axis=(1, 2)))[0][0]) for i in range(8)]
+    assert len(set(seen)) == 24              # no clip repeats inside an epoch
+    assert next(ims).shape == (8, 1, 28, 28)
