@@ -6,9 +6,9 @@ anything does, and there is no fallback path.
 """
 from . import _lib
 from .modules import (Noise, ODEFunc, PatchImageDiscriminator, VideoDiscriminator, VideoGenerator,
-                      VideoGeneratorMNIST, VideoGeneratorMNISTODE)
+                      VideoGeneratorMNIST, VideoGeneratorMNISTODE, VideoGeneratorMNISTODERNN)
 from .train import FusedAdam, GanTrainer, bce_with_logits_const, build_mnist, build_ucf, train_step
 
 __all__ = ["Noise", "ODEFunc", "PatchImageDiscriminator", "VideoDiscriminator", "VideoGenerator",
-           "VideoGeneratorMNIST", "VideoGeneratorMNISTODE", "FusedAdam", "GanTrainer", "bce_with_logits_const",
+           "VideoGeneratorMNIST", "VideoGeneratorMNISTODE", "VideoGeneratorMNISTODERNN", "FusedAdam", "GanTrainer", "bce_with_logits_const",
            "build_mnist", "build_ucf", "train_step", "_lib"]

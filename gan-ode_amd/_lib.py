@@ -14,7 +14,9 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH_OUT = 0, 1, 2, 3
 EPI_RAW, EPI_TANH = 0, 1
 FPROP, DGRAD = 0, 1
 OP_IGEMM, OP_WGRAD, OP_BN_FINALIZE, OP_BN_BWD, OP_ODE_FWD, OP_ODE_BWD, OP_BCE, OP_ADAM, OP_PACK = range(1, 10)
+OP_ODERNN_FWD, OP_ODERNN_BWD = 10, 11
 ODE_NPARAM = 2672
+ODERNN_NPARAM = 2176
 
 
 class ConvGeom(C.Structure):
@@ -70,6 +72,22 @@ class OdeBwdOp(C.Structure):
     KIND = OP_ODE_BWD
 
 
+class OdeRnnParams(C.Structure):
+    _fields_ = [(n, ptr) for n in "W1 b1 W2 b2 Wih Whh bih bhh".split()]
+
+
+class OdeRnnFwdOp(C.Structure):
+    _fields_ = [("p", OdeRnnParams), ("noise", ptr), ("content", ptr), ("sel_t", ptr), ("z", ptr), ("hs", ptr),
+                ("hp", ptr), ("nsteps", ptr), ("N", i32), ("T", i32), ("rtol", f32), ("atol", f32)]
+    KIND = OP_ODERNN_FWD
+
+
+class OdeRnnBwdOp(C.Structure):
+    _fields_ = [("p", OdeRnnParams), ("noise", ptr), ("hp", ptr), ("sel_t", ptr), ("gz", ptr), ("work", ptr),
+                ("grads", ptr), ("N", i32), ("T", i32), ("substeps", i32), ("accumulate", i32)]
+    KIND = OP_ODERNN_BWD
+
+
 class BceOp(C.Structure):
     _fields_ = [("logits", ptr), ("grad", ptr), ("loss", ptr), ("n", i64), ("target", f32), ("gscale", f32),
                 ("accumulate", i32), ("pad_", i32)]
@@ -88,11 +106,13 @@ class PackOp(C.Structure):
 
 
 _STRUCTS = {0: ConvGeom, OP_IGEMM: IgemmOp, OP_WGRAD: WgradOp, OP_BN_FINALIZE: BnFinalizeOp, OP_BN_BWD: BnBwdOp,
-            OP_ODE_FWD: OdeFwdOp, OP_ODE_BWD: OdeBwdOp, OP_BCE: BceOp, OP_ADAM: AdamOp, OP_PACK: PackOp}
+            OP_ODE_FWD: OdeFwdOp, OP_ODE_BWD: OdeBwdOp, OP_BCE: BceOp, OP_ADAM: AdamOp, OP_PACK: PackOp,
+            OP_ODERNN_FWD: OdeRnnFwdOp, OP_ODERNN_BWD: OdeRnnBwdOp}
 
 EXPORTS = ["gode_igemm", "gode_igemm_stats_rows", "gode_igemm_work_size", "gode_pack_size", "gode_pack_weights", "gode_wgrad",
            "gode_wgrad_work_size", "gode_wgrad_auto_splits", "gode_bn_finalize", "gode_bn_bwd",
-           "gode_bn_bwd_work_size", "gode_ode_fwd", "gode_ode_bwd", "gode_ode_bwd_work_size", "gode_bce_logits",
+           "gode_bn_bwd_work_size", "gode_ode_fwd", "gode_ode_bwd", "gode_ode_bwd_work_size", "gode_odernn_fwd",
+           "gode_odernn_bwd", "gode_odernn_bwd_work_size", "gode_bce_logits",
            "gode_adam_l2", "gode_adam_multi", "gode_scale", "gode_run", "gode_version", "gode_sizeof"]
 
 _lib = None
@@ -115,7 +135,7 @@ def lib():
         if L.gode_sizeof(kind) != C.sizeof(st):
             raise RuntimeError(f"ABI mismatch for op kind {kind}: C {L.gode_sizeof(kind)} != ctypes {C.sizeof(st)}")
     for name in ("gode_igemm", "gode_wgrad", "gode_bn_finalize", "gode_bn_bwd", "gode_ode_fwd", "gode_ode_bwd",
-                 "gode_bce_logits", "gode_adam_l2"):
+                 "gode_bce_logits", "gode_adam_l2", "gode_odernn_fwd", "gode_odernn_bwd"):
         getattr(L, name).argtypes = [ptr, ptr]
         getattr(L, name).restype = C.c_int
     L.gode_igemm_stats_rows.argtypes = [ptr]
@@ -131,6 +151,8 @@ def lib():
     L.gode_bn_bwd_work_size.restype = i64
     L.gode_ode_bwd_work_size.argtypes = [i32]
     L.gode_ode_bwd_work_size.restype = i64
+    L.gode_odernn_bwd_work_size.argtypes = [i32]
+    L.gode_odernn_bwd_work_size.restype = i64
     L.gode_scale.argtypes = [ptr, ptr, i64, f32, C.c_int, ptr]
     L.gode_adam_multi.argtypes = [ptr, i32, i64, f32, f32, f32, f32, f32, f32, i32, ptr]
     L.gode_run.argtypes = [ptr, ptr, i32, ptr]
@@ -160,5 +182,5 @@ class Program:
 def run_one(op, stream):
     fn = {OP_IGEMM: "gode_igemm", OP_WGRAD: "gode_wgrad", OP_BN_FINALIZE: "gode_bn_finalize", OP_BN_BWD: "gode_bn_bwd",
           OP_ODE_FWD: "gode_ode_fwd", OP_ODE_BWD: "gode_ode_bwd", OP_BCE: "gode_bce_logits",
-          OP_ADAM: "gode_adam_l2"}[op.KIND]
+          OP_ADAM: "gode_adam_l2", OP_ODERNN_FWD: "gode_odernn_fwd", OP_ODERNN_BWD: "gode_odernn_bwd"}[op.KIND]
     check(getattr(lib(), fn)(C.byref(op), stream), fn)

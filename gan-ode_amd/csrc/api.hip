@@ -15,6 +15,8 @@ extern "C" int gode_sizeof(int kind) {
     case GODE_OP_BCE: return (int)sizeof(gode_bce_op);
     case GODE_OP_ADAM: return (int)sizeof(gode_adam_op);
     case GODE_OP_PACK: return (int)sizeof(gode_pack_op);
+    case GODE_OP_ODERNN_FWD: return (int)sizeof(gode_odernn_fwd_op);
+    case GODE_OP_ODERNN_BWD: return (int)sizeof(gode_odernn_bwd_op);
   }
   return GODE_E_KIND;
 }
@@ -34,6 +36,8 @@ extern "C" int gode_run(const int32_t* kinds, const void* const* ops, int32_t n,
       case GODE_OP_ODE_BWD: rc = gode_ode_bwd((const gode_ode_bwd_op*)ops[i], stream); break;
       case GODE_OP_BCE: rc = gode_bce_logits((const gode_bce_op*)ops[i], stream); break;
       case GODE_OP_ADAM: rc = gode_adam_l2((const gode_adam_op*)ops[i], stream); break;
+      case GODE_OP_ODERNN_FWD: rc = gode_odernn_fwd((const gode_odernn_fwd_op*)ops[i], stream); break;
+      case GODE_OP_ODERNN_BWD: rc = gode_odernn_bwd((const gode_odernn_bwd_op*)ops[i], stream); break;
       case GODE_OP_PACK: {
         const gode_pack_op* p = (const gode_pack_op*)ops[i];
         rc = gode_pack_weights(&p->g, p->dir, p->w, p->wpack, p->co_perm, p->co_canon, stream);

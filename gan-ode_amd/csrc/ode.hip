@@ -14,36 +14,7 @@
 // through a 1.25 KB per-matrix LDS tile and is again an MFMA (k = trajectory).
 #include "common.h"
 
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-__device__ __forceinline__ f32x4 matvec(const f32x4 w, const f32x4 x, f32x4 c) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) c = MFMA16(w[r], x[r], c);
-  return c;
-}
-// tanh(x) = 1 - 2/(exp(2x)+1) on the hardware exp/rcp units (v_exp_f32, v_rcp_f32): absolute error ~1e-7, saturates
-// correctly at +-inf; libm's tanhf costs ~10x more instructions and dominated the solve (4 tanh per lane per RHS).
-__device__ __forceinline__ float fast_tanh(float x) {
-  const float t = __expf(2.f * x);
-  return 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
-}
-__device__ __forceinline__ f32x4 tanh4(const f32x4 u) {
-  return f32x4{fast_tanh(u[0]), fast_tanh(u[1]), fast_tanh(u[2]), fast_tanh(u[3])};
-}
-__device__ __forceinline__ f32x4 lrelu4(const f32x4 u) {
-  f32x4 o;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = u[r] > 0.f ? u[r] : 0.2f * u[r];
-  return o;
-}
-__device__ __forceinline__ f32x4 lrelu_grad4(const f32x4 pre, const f32x4 gr) {
-  f32x4 o;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = pre[r] > 0.f ? gr[r] : 0.2f * gr[r];
-  return o;
-}
+#include "ode_common.h"
 
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) ode_fwd_kernel(const gode_ode_fwd_op a) {
@@ -129,20 +100,6 @@ extern "C" int gode_ode_fwd(const gode_ode_fwd_op* op, void* stream) {
 #define OFF_B1 2384
 #define OFF_W2 2400
 #define OFF_B2 2656
-#define LDT 20  // LDS row stride (floats) of a 16x16 transpose tile: conflict-free b128 writes / b32 reads
-
-// sum over the 16 trajectories of a wave (lanes sharing g)
-__device__ __forceinline__ f32x4 sum_over_samples(f32x4 v) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    v[r] += __shfl_xor(v[r], 1);
-    v[r] += __shfl_xor(v[r], 2);
-    v[r] += __shfl_xor(v[r], 4);
-    v[r] += __shfl_xor(v[r], 8);
-  }
-  return v;
-}
-
 __global__ void __launch_bounds__(64) ode_bwd_kernel(const gode_ode_bwd_op a) {
   __shared__ __attribute__((aligned(16))) float tile[4][16 * LDT];
   const int l = threadIdx.x, s = l & 15, g = l >> 4;

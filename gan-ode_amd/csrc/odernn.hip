@@ -1,0 +1,300 @@
+// odernn.hip -- the ODE-RNN motion latent (models/mocogan_ode_rnn.py:41-53):
+//   h_0 ~ N(0,1);  per frame:  h' = odeint_adjoint(ODEFunc, h, [0,1])[-1]  (torchdiffeq default: dopri5, rtol 1e-7,
+//   atol 1e-9),  h = GRUCell(e_t, h'),  e_t ~ N(0,1);  latent row t = h_{t+1}.
+//
+// Forward: one launch for all T frames.  dopri5 with torchdiffeq's controller (initial step selection, accept iff
+// RMS(err/tol) <= 1, factor clipping 0.2..10, safety 0.9, 4th-order dense output at t = 1), the error norm taken
+// JOINTLY over all trajectories of the workgroup (up to 256) as torchdiffeq takes it over the batch.  Every 16x16
+// product (ODEFunc and the six GRU gate products) is a chained v_mfma_f32_16x16x4_f32 tile as in ode.hip.
+// Backward: GRU backward + continuous adjoint of each unit-interval solve.  torchdiffeq integrates the adjoint
+// adaptively to the same 1e-7 tolerance; here it is integrated with `substeps` fixed reverse-time Kutta-3/8 steps
+// (default 32: 4th-order error ~1e-6 relative, far inside the 2e-4 gradient tolerance) -- a recorded deviation in
+// HOW the same continuous adjoint is discretised, not in what is computed.
+#include "ode_common.h"
+
+#define RNN_NPARAM 2176
+#define RO_W1 0
+#define RO_B1 256
+#define RO_W2 272
+#define RO_B2 528
+#define RO_WIH 544
+#define RO_WHH 1312
+#define RO_BIH 2080
+#define RO_BHH 2128
+
+__device__ __forceinline__ float block_sum(float v, float* red, int nw) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < nw; ++w) s += red[w];
+  return s;
+}
+__device__ __forceinline__ float sq4(const f32x4 v) { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+__device__ __forceinline__ f32x4 abs4(const f32x4 v) { return f32x4{fabsf(v[0]), fabsf(v[1]), fabsf(v[2]), fabsf(v[3])}; }
+__device__ __forceinline__ f32x4 max4(const f32x4 a, const f32x4 b) {
+  return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])};
+}
+
+__global__ void __launch_bounds__(1024) odernn_fwd_kernel(const gode_odernn_fwd_op a) {
+  __shared__ float red[16];
+  const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int s = l & 15, g = l >> 4;
+  const int n = blockIdx.x * 256 + wv * 16 + s;
+  const bool valid = n < a.N;
+  const int T = a.T;
+  const int nblk = (a.N - blockIdx.x * 256) < 256 ? (a.N - blockIdx.x * 256) : 256;
+  const float inv_count = 1.f / (float)(nblk * 16);
+
+  const f32x4 w1 = ld4(a.p.W1 + s * 16 + 4 * g), w2 = ld4(a.p.W2 + s * 16 + 4 * g);
+  const f32x4 b1 = ld4(a.p.b1 + 4 * g), b2 = ld4(a.p.b2 + 4 * g);
+  auto f = [&](const f32x4 yy) { return matvec(w2, tanh4(matvec(w1, yy, b1)), b2); };
+  f32x4 wih[3], whh[3], bih[3], bhh[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    wih[q] = ld4(a.p.Wih + (16 * q + s) * 16 + 4 * g); whh[q] = ld4(a.p.Whh + (16 * q + s) * 16 + 4 * g);
+    bih[q] = ld4(a.p.bih + 16 * q + 4 * g); bhh[q] = ld4(a.p.bhh + 16 * q + 4 * g);
+  }
+  auto rms = [&](const f32x4 v) { return sqrtf(block_sum(valid ? sq4(v) : 0.f, red, nw) * inv_count); };
+
+  const int tsel = (a.sel_t && valid) ? a.sel_t[n] : -1;
+  f32x4 h = valid ? ld4(a.noise + (int64_t)n * 16 + 4 * g) : zero4();
+  if (valid && a.hs) *reinterpret_cast<f32x4*>(a.hs + ((int64_t)n * (T + 1)) * 16 + 4 * g) = h;
+
+  for (int t = 0; t < T; ++t) {
+    // ---- h' = y(1), y' = f(y), y(0) = h : dopri5 with torchdiffeq's controller
+    f32x4 y0 = h, f0 = f(h), yend = h;
+    float dt;
+    {
+      const f32x4 sc = a.atol + abs4(y0) * a.rtol;
+      const float d0 = rms(y0 / sc), d1 = rms(f0 / sc);
+      const float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
+      const f32x4 f1 = f(y0 + h0 * f0);
+      const float d2 = rms((f1 - f0) / sc) / h0;
+      const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
+      dt = fminf(100.f * h0, h1);
+    }
+    float tcur = 0.f;
+    int steps = 0;
+    for (; steps < 100000; ++steps) {
+      const f32x4 k1 = f0;
+      const f32x4 k2 = f(y0 + dt * (0.2f * k1));
+      const f32x4 k3 = f(y0 + dt * ((3.f / 40.f) * k1 + (9.f / 40.f) * k2));
+      const f32x4 k4 = f(y0 + dt * ((44.f / 45.f) * k1 + (-56.f / 15.f) * k2 + (32.f / 9.f) * k3));
+      const f32x4 k5 = f(y0 + dt * ((19372.f / 6561.f) * k1 + (-25360.f / 2187.f) * k2 + (64448.f / 6561.f) * k3 +
+                                    (-212.f / 729.f) * k4));
+      const f32x4 k6 = f(y0 + dt * ((9017.f / 3168.f) * k1 + (-355.f / 33.f) * k2 + (46732.f / 5247.f) * k3 +
+                                    (49.f / 176.f) * k4 + (-5103.f / 18656.f) * k5));
+      const f32x4 y1 = y0 + dt * ((35.f / 384.f) * k1 + (500.f / 1113.f) * k3 + (125.f / 192.f) * k4 +
+                                  (-2187.f / 6784.f) * k5 + (11.f / 84.f) * k6);
+      const f32x4 k7 = f(y1);
+      const f32x4 err = dt * ((35.f / 384.f - 1951.f / 21600.f) * k1 + (500.f / 1113.f - 22642.f / 50085.f) * k3 +
+                              (125.f / 192.f - 451.f / 720.f) * k4 + (-2187.f / 6784.f + 12231.f / 42400.f) * k5 +
+                              (11.f / 84.f - 649.f / 6300.f) * k6 + (-1.f / 60.f) * k7);
+      const f32x4 tol = a.atol + a.rtol * max4(abs4(y0), abs4(y1));
+      const float ratio = rms(err / tol);
+      const bool accept = ratio <= 1.f;
+      if (accept) {
+        if (tcur + dt >= 1.f) {   // dense output (4th-order fit through the mid-point) at t = 1
+          const f32x4 ymid = y0 + dt * ((6025192743.f / 30085553152.f / 2.f) * k1 + (51252292925.f / 65400821598.f / 2.f) * k3 +
+                                        (-2691868925.f / 45128329728.f / 2.f) * k4 + (187940372067.f / 1594534317056.f / 2.f) * k5 +
+                                        (-1776094331.f / 19743644256.f / 2.f) * k6 + (11237099.f / 235043384.f / 2.f) * k7);
+          const f32x4 ca = 2.f * dt * (k7 - k1) - 8.f * (y1 + y0) + 16.f * ymid;
+          const f32x4 cb = dt * (5.f * k1 - 3.f * k7) + 18.f * y0 + 14.f * y1 - 32.f * ymid;
+          const f32x4 cc = dt * (k7 - 4.f * k1) - 11.f * y0 - 5.f * y1 + 16.f * ymid;
+          const f32x4 cd = dt * k1;
+          const float x = (1.f - tcur) / dt;
+          yend = y0 + x * (cd + x * (cc + x * (cb + x * ca)));
+          ++steps;
+          break;
+        }
+        tcur += dt; y0 = y1; f0 = k7;
+      }
+      float fac;
+      if (ratio == 0.f) fac = 10.f;
+      else { fac = 0.9f * powf(ratio, -0.2f); fac = fminf(10.f, fmaxf(fac, ratio < 1.f ? 1.f : 0.2f)); }
+      dt *= fac;
+    }
+    if (a.nsteps && threadIdx.x == 0) a.nsteps[blockIdx.x * T + t] = steps;
+    if (valid && a.hp) *reinterpret_cast<f32x4*>(a.hp + ((int64_t)n * T + t) * 16 + 4 * g) = yend;
+    // ---- GRUCell(e_t, h')
+    const f32x4 e = valid ? ld4(a.noise + ((int64_t)(t + 1) * a.N + n) * 16 + 4 * g) : zero4();
+    const f32x4 r = sigmoid4(matvec(wih[0], e, bih[0]) + matvec(whh[0], yend, bhh[0]));
+    const f32x4 zg = sigmoid4(matvec(wih[1], e, bih[1]) + matvec(whh[1], yend, bhh[1]));
+    const f32x4 nn = tanh4(matvec(wih[2], e, bih[2]) + r * matvec(whh[2], yend, bhh[2]));
+    h = (1.f - zg) * nn + zg * yend;
+    if (valid) {
+      if (a.hs) *reinterpret_cast<f32x4*>(a.hs + ((int64_t)n * (T + 1) + t + 1) * 16 + 4 * g) = h;
+      if (a.sel_t == nullptr) *reinterpret_cast<f32x4*>(a.z + ((int64_t)n * T + t) * 72 + 4 * g) = h;
+      else if (t == tsel) *reinterpret_cast<f32x4*>(a.z + (int64_t)n * 72 + 4 * g) = h;
+    }
+  }
+}
+
+// content columns 16..65 of the latent rows + zero pad (same layout as gode_ode_fwd writes)
+__global__ void __launch_bounds__(256) latent_content_kernel(const float* content, float* z, int N, int rows_per) {
+  const int64_t total4 = (int64_t)N * rows_per * 14;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / 14; const int q = (int)(i - row * 14);
+    const int64_t nn = row / rows_per;
+    f32x4 v = zero4();
+    if (q < 12) v = f32x4{content[nn * 50 + 4 * q], content[nn * 50 + 4 * q + 1], content[nn * 50 + 4 * q + 2], content[nn * 50 + 4 * q + 3]};
+    else if (q == 12) v = f32x4{content[nn * 50 + 48], content[nn * 50 + 49], 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(z + row * 72 + 16 + 4 * q) = v;
+  }
+}
+
+extern "C" int gode_odernn_fwd(const gode_odernn_fwd_op* op, void* stream) {
+  if (!op || !op->noise || !op->z || op->N <= 0 || op->T < 1 || !(op->rtol > 0.f) || !(op->atol >= 0.f)) return GODE_E_ARG;
+  if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2 || !op->p.Wih || !op->p.Whh || !op->p.bih || !op->p.bhh) return GODE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (op->content) {
+    const int rows_per = op->sel_t ? 1 : op->T;
+    int64_t total4 = (int64_t)op->N * rows_per * 14;
+    int blocks = (int)((total4 + 255) / 256); if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(latent_content_kernel, dim3(blocks), dim3(256), 0, st, op->content, op->z, op->N, rows_per);
+    GODE_LAUNCH_CHECK();
+  }
+  const int nblocks = (op->N + 255) / 256;
+  const int per = op->N < 256 ? op->N : 256;
+  const int threads = ((per + 15) / 16) * 64;     // every workgroup gets this many waves; trailing lanes are masked
+  hipLaunchKernelGGL(odernn_fwd_kernel, dim3(nblocks), dim3(threads), 0, st, *op);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) odernn_bwd_kernel(const gode_odernn_bwd_op a) {
+  __shared__ __attribute__((aligned(16))) float tile[2][16 * LDT];
+  const int l = threadIdx.x, s = l & 15, g = l >> 4;
+  const int n = blockIdx.x * 16 + s;
+  const bool valid = n < a.N;
+  const int T = a.T;
+  float* part = a.work + (int64_t)blockIdx.x * RNN_NPARAM;
+
+  const f32x4 w1 = ld4(a.p.W1 + s * 16 + 4 * g), w2 = ld4(a.p.W2 + s * 16 + 4 * g);
+  const f32x4 b1 = ld4(a.p.b1 + 4 * g), b2 = ld4(a.p.b2 + 4 * g);
+  f32x4 w1t, w2t, wih[3], whh[3], bih[3], bhh[3], whht[3];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { w1t[r] = a.p.W1[(4 * g + r) * 16 + s]; w2t[r] = a.p.W2[(4 * g + r) * 16 + s]; }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    wih[q] = ld4(a.p.Wih + (16 * q + s) * 16 + 4 * g); whh[q] = ld4(a.p.Whh + (16 * q + s) * 16 + 4 * g);
+    bih[q] = ld4(a.p.bih + 16 * q + 4 * g); bhh[q] = ld4(a.p.bhh + 16 * q + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) whht[q][r] = a.p.Whh[(16 * q + 4 * g + r) * 16 + s];   // (Whh_q)^T operand
+  }
+  auto outer = [&](f32x4 dst, const f32x4 P, const f32x4 Q) {
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(&tile[0][s * LDT + 4 * g]) = P;
+    *reinterpret_cast<f32x4*>(&tile[1][s * LDT + 4 * g]) = Q;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst = MFMA16(tile[0][(4 * g + r) * LDT + s], tile[1][(4 * g + r) * LDT + s], dst);
+    return dst;
+  };
+  f32x4 gW1 = zero4(), gW2 = zero4(), gb1 = zero4(), gb2 = zero4();
+  f32x4 gWih[3], gWhh[3], gbih[3], gbhh[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) { gWih[q] = zero4(); gWhh[q] = zero4(); gbih[q] = zero4(); gbhh[q] = zero4(); }
+  f32x4 ky, ka;
+  auto stage = [&](const f32x4 ys, const f32x4 as, float c) {
+    const f32x4 hh = tanh4(matvec(w1, ys, b1));
+    const f32x4 fv = matvec(w2, hh, b2);
+    const f32x4 du = matvec(w2t, as, zero4()) * (1.f - hh * hh);
+    ka = matvec(w1t, du, zero4());
+    ky = -fv;
+    const f32x4 ca = c * as, cdu = c * du;
+    gb2 += ca; gb1 += cdu;
+    gW2 = outer(gW2, ca, hh);
+    gW1 = outer(gW1, cdu, ys);
+  };
+  const int tsel = (a.sel_t && valid) ? a.sel_t[n] : -1;
+  auto upstream = [&](int t) {
+    if (!valid) return zero4();
+    if (a.sel_t == nullptr) return ld4(a.gz + ((int64_t)n * T + t) * 72 + 4 * g);
+    return t == tsel ? ld4(a.gz + (int64_t)n * 72 + 4 * g) : zero4();
+  };
+  const float third = 1.0f / 3.0f, dt = 1.f / (float)a.substeps;
+  f32x4 carry = zero4();
+  for (int t = T - 1; t >= 0; --t) {
+    const f32x4 gh = carry + upstream(t);                                        // dL/dh_{t+1}
+    const f32x4 e = valid ? ld4(a.noise + ((int64_t)(t + 1) * a.N + n) * 16 + 4 * g) : zero4();
+    const f32x4 hp = valid ? ld4(a.hp + ((int64_t)n * T + t) * 16 + 4 * g) : zero4();
+    // GRU recompute + backward
+    const f32x4 r = sigmoid4(matvec(wih[0], e, bih[0]) + matvec(whh[0], hp, bhh[0]));
+    const f32x4 zg = sigmoid4(matvec(wih[1], e, bih[1]) + matvec(whh[1], hp, bhh[1]));
+    const f32x4 hn = matvec(whh[2], hp, bhh[2]);
+    const f32x4 nn = tanh4(matvec(wih[2], e, bih[2]) + r * hn);
+    const f32x4 dn_pre = gh * (1.f - zg) * (1.f - nn * nn);
+    const f32x4 dz_pre = gh * (hp - nn) * zg * (1.f - zg);
+    const f32x4 dr_pre = dn_pre * hn * r * (1.f - r);
+    const f32x4 dgi[3] = {dr_pre, dz_pre, dn_pre};
+    const f32x4 dgh[3] = {dr_pre, dz_pre, dn_pre * r};
+    f32x4 adj = gh * zg;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      gbih[q] += dgi[q]; gbhh[q] += dgh[q];
+      gWih[q] = outer(gWih[q], dgi[q], e);
+      gWhh[q] = outer(gWhh[q], dgh[q], hp);
+      adj = matvec(whht[q], dgh[q], adj);
+    }
+    // continuous adjoint of h' = y(1), y(0) = h_t, reverse time, fixed Kutta-3/8 substeps
+    f32x4 y = hp;
+    for (int ss = 0; ss < a.substeps; ++ss) {
+      stage(y, adj, dt * 0.125f);
+      const f32x4 ky1 = ky, ka1 = ka;
+      stage(y + dt * ky1 * third, adj + dt * ka1 * third, 3.f * dt * 0.125f);
+      const f32x4 ky2 = ky, ka2 = ka;
+      stage(y + dt * (ky2 - ky1 * third), adj + dt * (ka2 - ka1 * third), 3.f * dt * 0.125f);
+      const f32x4 ky3 = ky, ka3 = ka;
+      stage(y + dt * (ky1 - ky2 + ky3), adj + dt * (ka1 - ka2 + ka3), dt * 0.125f);
+      y = y + (ky1 + 3.f * (ky2 + ky3) + ky) * dt * 0.125f;
+      adj = adj + (ka1 + 3.f * (ka2 + ka3) + ka) * dt * 0.125f;
+    }
+    carry = adj;                                                                 // dL/dh_t
+  }
+  const f32x4 sb1 = sum_over_samples(gb1), sb2 = sum_over_samples(gb2);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    part[RO_W1 + (4 * g + r) * 16 + s] = gW1[r];
+    part[RO_W2 + (4 * g + r) * 16 + s] = gW2[r];
+  }
+  if (s == 0) { *reinterpret_cast<f32x4*>(part + RO_B1 + 4 * g) = sb1; *reinterpret_cast<f32x4*>(part + RO_B2 + 4 * g) = sb2; }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const f32x4 si = sum_over_samples(gbih[q]), sh = sum_over_samples(gbhh[q]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      part[RO_WIH + (16 * q + 4 * g + r) * 16 + s] = gWih[q][r];
+      part[RO_WHH + (16 * q + 4 * g + r) * 16 + s] = gWhh[q][r];
+    }
+    if (s == 0) { *reinterpret_cast<f32x4*>(part + RO_BIH + 16 * q + 4 * g) = si; *reinterpret_cast<f32x4*>(part + RO_BHH + 16 * q + 4 * g) = sh; }
+  }
+}
+
+__global__ void __launch_bounds__(256) odernn_bwd_reduce_kernel(const float* work, float* grads, int nblk, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= RNN_NPARAM) return;
+  float sacc = 0.f;
+  for (int b = 0; b < nblk; ++b) sacc += work[(int64_t)b * RNN_NPARAM + i];
+  grads[i] = accumulate ? grads[i] + sacc : sacc;
+}
+
+extern "C" int64_t gode_odernn_bwd_work_size(int32_t N) { return (int64_t)((N + 15) / 16) * RNN_NPARAM; }
+
+extern "C" int gode_odernn_bwd(const gode_odernn_bwd_op* op, void* stream) {
+  if (!op || !op->noise || !op->hp || !op->gz || !op->work || !op->grads || op->N <= 0 || op->T < 1 || op->substeps < 1)
+    return GODE_E_ARG;
+  if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2 || !op->p.Wih || !op->p.Whh || !op->p.bih || !op->p.bhh) return GODE_E_ARG;
+  const int nblk = (op->N + 15) / 16;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(odernn_bwd_kernel, dim3(nblk), dim3(64), 0, st, *op);
+  GODE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(odernn_bwd_reduce_kernel, dim3((RNN_NPARAM + 255) / 256), dim3(256), 0, st, op->work, op->grads, nblk,
+                     op->accumulate);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}

@@ -151,7 +151,11 @@ class _GenPlan:
         self.bwd_op.grads = grads.data_ptr()
         L.run_one(self.bwd_op, stream_ptr())
         self.busy = False
-        return views, grads
+        offs = [(0, 1024, (64, 16)), (1024, 64, (64,)), (1088, 1024, (16, 64)), (2112, 16, (16,)),
+                (2128, 256, (16, 16)), (2384, 16, (16,)), (2400, 256, (16, 16)), (2656, 16, (16,))]
+        if self._ode_ptrs[0] is None:
+            offs = offs[4:]
+        return views, [grads[o:o + n].view(shp) for o, n, shp in offs]
 
 
 class _GenFn(torch.autograd.Function):
@@ -166,19 +170,14 @@ class _GenFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         plan = ctx.plan
-        views, og = plan.backward(gout)
+        views, motion = plan.backward(gout)
         grads = []
         for wv, gv, bv in views:
             grads.append(wv)
             if gv is not None:
                 grads += [gv, bv]
-        assert len(grads) == ctx.n_dec
-        offs = [(0, 1024, (64, 16)), (1024, 64, (64,)), (1088, 1024, (16, 64)), (2112, 16, (16,)),
-                (2128, 256, (16, 16)), (2384, 16, (16,)), (2400, 256, (16, 16)), (2656, 16, (16,))]
-        n_ode = ctx.n_params - ctx.n_dec
-        for o, n, shp in (offs if n_ode == 8 else offs[4:]):
-            grads.append(og[o:o + n].view(shp))
-        return (None, None, None, None, None, None, None, *grads)
+        assert len(grads) == ctx.n_dec and len(motion) == ctx.n_params - ctx.n_dec
+        return (None, None, None, None, None, None, None, *grads, *motion)
 
 
 class VideoGenerator(nn.Module):
@@ -187,6 +186,7 @@ class VideoGenerator(nn.Module):
     output interval) sub-divides each interval."""
 
     mnist = False
+    _plan_cls = None   # set below (_GenPlan)
 
     def __init__(self, n_channels, dim_z_content, dim_z_category, dim_z_motion, video_length, ode_fn=ODEFunc,
                  dim_hidden=None, linear=True, ngf=64):
@@ -295,7 +295,7 @@ class VideoGenerator(nn.Module):
 
     def _run(self, n_traj, T, select, x, content, sel):
         _require_gpu(self.main[0].weight, type(self).__name__)
-        plan = self._pool.get((n_traj, T, select), lambda: _GenPlan(self, n_traj, T, select))
+        plan = self._pool.get((n_traj, T, select), lambda: self._plan_cls(self, n_traj, T, select))
         dec, ode = self._param_list()
         # (grad mode is off inside Function.forward, so decide here whether the plan must be kept for a backward)
         keep = torch.is_grad_enabled() and any(p.requires_grad for p in dec + ode)
@@ -335,6 +335,9 @@ class VideoGenerator(nn.Module):
         raise RuntimeError("use sample_videos()/sample_images() (the reference never calls forward())")
 
 
+VideoGenerator._plan_cls = _GenPlan
+
+
 class VideoGeneratorMNIST(VideoGenerator):
     """28x28 decoder variant (models/mocogan_ode.py:57-111)."""
 
@@ -355,6 +358,93 @@ class VideoGeneratorMNISTODE(VideoGeneratorMNIST):
         hid = dim_hidden if dim_hidden else self.dim_z_motion
         self.ode_fn = ode_fn(dim=self.dim_z_motion, dim_hidden=hid)   # re-created, as the reference does
         self.linear = self._make_prenet(linear)
+
+
+class _RnnGenPlan(_GenPlan):
+    """ODE-RNN latent (gode_odernn_fwd/bwd) + decoder.  x_host carries the noise stack [T+1, n, 16]."""
+
+    def __init__(self, gen, n_traj, T, select):
+        super().__init__(gen, n_traj, T, select)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.noise = torch.empty(T + 1, n_traj, 16, **f32)
+        self.hp = torch.empty(n_traj, T, 16, **f32)
+        self.nsteps = torch.zeros((n_traj + 255) // 256 * T, dtype=torch.int32, device=self.device)
+        self.rnn_work = torch.empty(L.lib().gode_odernn_bwd_work_size(n_traj), **f32)
+        self._ring = [dict(x=torch.empty(T + 1, n_traj, 16).pin_memory(), c=torch.empty(n_traj, 50).pin_memory(),
+                           s=torch.zeros(n_traj, dtype=torch.int32).pin_memory(), ev=None) for _ in range(4)]
+        self.x = self.noise    # the staging code of the base class copies the noise stack into self.x
+
+    def _rnn_params(self):
+        g = self.gen
+        f, r = g.ode_fn.fn, g.recurrent
+        return (f[0].weight, f[0].bias, f[2].weight, f[2].bias, r.weight_ih, r.weight_hh, r.bias_ih, r.bias_hh)
+
+    def _programs(self):
+        ptrs = tuple(dptr(p) for p in self._rnn_params())
+        if ptrs != self._ode_ptrs:
+            self._ode_ptrs = ptrs
+            op = L.OdeRnnParams(*ptrs)
+            self.fwd_op = L.OdeRnnFwdOp(p=op, noise=dptr(self.noise), content=dptr(self.content), sel_t=dptr(self.sel),
+                                        z=dptr(self.stack.x_in), hs=None, hp=dptr(self.hp), nsteps=dptr(self.nsteps),
+                                        N=self.n, T=self.T, rtol=self.gen.ode_rtol, atol=self.gen.ode_atol)
+            self.bwd_op = L.OdeRnnBwdOp(p=op, noise=dptr(self.noise), hp=dptr(self.hp), sel_t=dptr(self.sel), gz=None,
+                                        work=dptr(self.rnn_work), grads=None, N=self.n, T=self.T,
+                                        substeps=self.gen.adjoint_substeps, accumulate=0)
+            self.fwd_prog = L.Program([self.fwd_op])
+        self.fwd_op.rtol, self.fwd_op.atol = self.gen.ode_rtol, self.gen.ode_atol
+        self.bwd_op.substeps = self.gen.adjoint_substeps
+
+    def backward(self, gout):
+        flat, views, gz = self.stack.backward(gout, need_input_grad=True)
+        grads = torch.empty(L.ODERNN_NPARAM, dtype=torch.float32, device=self.device)
+        self.bwd_op.gz = gz.data_ptr()
+        self.bwd_op.grads = grads.data_ptr()
+        L.run_one(self.bwd_op, stream_ptr())
+        self.busy = False
+        offs = [(0, 256, (16, 16)), (256, 16, (16,)), (272, 256, (16, 16)), (528, 16, (16,)),
+                (544, 768, (48, 16)), (1312, 768, (48, 16)), (2080, 48, (48,)), (2128, 48, (48,))]
+        return views, [grads[o:o + n].view(shp) for o, n, shp in offs]
+
+
+class VideoGeneratorMNISTODERNN(VideoGeneratorMNIST):
+    """ODE-RNN generator (models/mocogan_ode_rnn.py:21-53): per frame the hidden state is evolved by the Neural ODE
+    over a unit interval (torchdiffeq default solver: dopri5, rtol 1e-7, atol 1e-9) and then updated by the GRU cell
+    with fresh noise.  The pre-net `linear` is constructed (state_dict parity) but unused, as in the reference.
+    Noise: the reference calls T.FloatTensor(n, d).normal_() (models/mocogan.py:297-301), i.e. the DEVICE generator on
+    a GPU; here it is always drawn from the global torch CPU generator in the same order and copied to the device, so
+    that runs are comparable with the CPU oracle at identical seeds ("ROCm .cuda() semantics")."""
+
+    _plan_cls = _RnnGenPlan
+    ode_rtol, ode_atol = 1e-7, 1e-9
+    adjoint_substeps = 32
+
+    def _init_ode_parts(self, ode_fn, dim_hidden, linear, dim_z, ngf):
+        super()._init_ode_parts(ode_fn, dim_hidden, linear, dim_z, ngf)
+        hid = dim_hidden if dim_hidden else self.dim_z_motion
+        self.ode_fn = ode_fn(dim=self.dim_z_motion, dim_hidden=hid)
+        self.linear = self._make_prenet(linear)
+
+    def _param_list(self):
+        dec, _ = super()._param_list()
+        f, r = self.ode_fn.fn, self.recurrent
+        return dec, [f[0].weight, f[0].bias, f[2].weight, f[2].bias, r.weight_ih, r.weight_hh, r.bias_ih, r.bias_hh]
+
+    def _draw(self, num_samples, video_len):
+        """content (NumPy) first, then h_0 and one e_t per frame from FloatTensor(...).normal_()
+        (models/mocogan.py:252,297-301; mocogan_ode_rnn.py:44-47)."""
+        content = np.random.normal(0, 1, (num_samples, self.dim_z_content)).astype(np.float32)
+        noise = torch.stack([torch.FloatTensor(num_samples, self.dim_z_motion).normal_() for _ in range(video_len + 1)])
+        return torch.from_numpy(content), noise
+
+    def sample_images(self, num_samples):
+        T = self.video_length
+        n_all = num_samples * T * 2
+        content, noise = self._draw(n_all, T)
+        j = np.sort(np.random.choice(n_all * T, num_samples, replace=False)).astype(np.int64)
+        traj = torch.from_numpy(j // T)
+        sel = torch.from_numpy((j % T).astype(np.int32))
+        h = self._run(num_samples, T, True, noise[:, traj].contiguous(), content[traj].contiguous(), sel)
+        return h.view(num_samples, h.size(2), h.size(3), self.n_channels).permute(0, 3, 1, 2), None
 
 
 # ==================================================================================================================

@@ -152,6 +152,34 @@ int gode_ode_bwd(const gode_ode_bwd_op* op, void* stream);
 int64_t gode_ode_bwd_work_size(int32_t N);
 #define GODE_ODE_NPARAM 2672
 
+/* ---- ODE-RNN motion latent (models/mocogan_ode_rnn.py:41-53) -------------------------------
+ * per frame: h' = odeint_adjoint(ODEFunc, h, [0,1])[-1] with torchdiffeq's default dopri5 (rtol, atol; error norm
+ * joint over the trajectories of a workgroup, <= 256), h = GRUCell(e_t, h').  noise[T+1][N][16] = h_0, e_0..e_{T-1}
+ * drawn on the host.  z / content / sel_t as in gode_ode_fwd (row t = h_{t+1}).  hs[N][T+1][16], hp[N][T][16]
+ * (post-ODE states) are kept for the backward; nsteps[ceil(N/256)][T] (nullable) counts dopri5 trial steps. */
+typedef struct gode_odernn_params {
+  const float* W1; const float* b1; const float* W2; const float* b2;         /* ODEFunc */
+  const float* Wih; const float* Whh; const float* bih; const float* bhh;     /* GRUCell(16,16): [48,16]x2, [48]x2 */
+} gode_odernn_params;
+typedef struct gode_odernn_fwd_op {
+  gode_odernn_params p;
+  const float* noise; const float* content; const int32_t* sel_t;
+  float* z; float* hs; float* hp; int32_t* nsteps;
+  int32_t N, T; float rtol, atol;
+} gode_odernn_fwd_op;
+int gode_odernn_fwd(const gode_odernn_fwd_op* op, void* stream);
+/* backward: GRU backward + continuous adjoint of every unit-interval solve, discretised with `substeps` fixed
+ * reverse-time Kutta-3/8 steps (torchdiffeq integrates the same adjoint adaptively to 1e-7; 32 substeps agree to
+ * ~1e-6).  grads: 2176 floats = W1,b1,W2,b2,Wih,Whh,bih,bhh.  work >= gode_odernn_bwd_work_size floats. */
+typedef struct gode_odernn_bwd_op {
+  gode_odernn_params p;
+  const float* noise; const float* hp; const int32_t* sel_t; const float* gz;
+  float* work; float* grads; int32_t N, T, substeps, accumulate;
+} gode_odernn_bwd_op;
+int gode_odernn_bwd(const gode_odernn_bwd_op* op, void* stream);
+int64_t gode_odernn_bwd_work_size(int32_t N);
+#define GODE_ODERNN_NPARAM 2176
+
 /* ---- loss and optimiser (mnist_moco_ode.py:86-89) ------------------------------------------------------------
  * BCE-with-logits, mean reduced, constant target: loss (+)= mean(max(x,0) - x*t + log1p(exp(-|x|))) and
  * g[i] = gscale*(sigmoid(x[i]) - t)/n.  loss is one device float; accumulate!=0 adds to it. */
@@ -175,7 +203,8 @@ int gode_scale(float* out, const float* a, int64_t n, float alpha, int accumulat
 
 /* ---- program runner: executes n ops back to back on the stream (one host call per network pass) -------------*/
 enum { GODE_OP_IGEMM = 1, GODE_OP_WGRAD = 2, GODE_OP_BN_FINALIZE = 3, GODE_OP_BN_BWD = 4, GODE_OP_ODE_FWD = 5,
-       GODE_OP_ODE_BWD = 6, GODE_OP_BCE = 7, GODE_OP_ADAM = 8, GODE_OP_PACK = 9 };
+       GODE_OP_ODE_BWD = 6, GODE_OP_BCE = 7, GODE_OP_ADAM = 8, GODE_OP_PACK = 9, GODE_OP_ODERNN_FWD = 10,
+       GODE_OP_ODERNN_BWD = 11 };
 typedef struct gode_pack_op {
   gode_conv_geom g; int32_t dir, co_canon; const float* w; float* wpack; const int32_t* co_perm;
 } gode_pack_op;

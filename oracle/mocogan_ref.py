@@ -106,6 +106,33 @@ class Generator(nn.Module):
         return self.main(z.view(z.size(0), z.size(1), 1, 1)), None
 
 
+class GeneratorOdeRnn(Generator):
+    """VideoGeneratorMNISTODERNN (/root/reference/models/mocogan_ode_rnn.py:21-53; un-importable as shipped because
+    of `on_dev`, restated here): per frame h' = odeint_adjoint(ode_fn, h, [0, 1])[-1] with torchdiffeq's DEFAULT
+    solver (dopri5, rtol 1e-7, atol 1e-9), then h = GRUCell(e_t, h').  The pre-net `linear` exists but is unused.
+    Noise comes from the legacy FloatTensor(...).normal_() calls of models/mocogan.py:297-301 (global torch CPU
+    generator); parity for this class is unpinned twice over (no fixture, torchdiffeq absent)."""
+
+    def _normal(self, n):
+        return torch.FloatTensor(n, self.dim_z_motion).normal_().to(self._dtype())
+
+    def sample_z_m(self, n, video_len=None):
+        T = video_len or self.video_length
+        h = [self._normal(n)]
+        t01 = torch.tensor([0, 1]).float().to(self._dtype())
+        for _ in range(T):
+            e = self._normal(n)
+            hp = ode_ref.odeint_adjoint(self.ode_fn, h[-1], t01)[-1]
+            h.append(self.recurrent(e, hp))
+        return torch.cat([k.view(-1, 1, self.dim_z_motion) for k in h[1:]], dim=1).view(-1, self.dim_z_motion)
+
+
+def build_mnist_odernn(ngf=64, ndf=64):
+    """mnist_moco_ode_rnn.py:75-78 (same discriminators, ODE-RNN generator)."""
+    return (GeneratorOdeRnn(1, 50, 0, 16, 16, ngf=ngf, mnist=True), VideoDisc(1, ksize=2, ndf=ndf),
+            PatchImageDisc(1, ndf=ndf))
+
+
 def _noise_slot():
     return nn.Identity()  # Noise(use_noise=False) is the identity (mocogan.py:20-29); keeps Sequential indices
 

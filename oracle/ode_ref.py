@@ -196,7 +196,7 @@ def dopri5_solve(f, y0, t, rtol=1e-7, atol=1e-9, norm=_rms, safety=0.9, ifactor=
 # --------------------------------------------------------------------------------------------------------------
 # public surface used by the torchdiffeq shim
 # --------------------------------------------------------------------------------------------------------------
-def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None):
+def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, _norm=None):
     """Plain (autograd-transparent) solve.  Tuple states and reversed time are supported because the adjoint
     pass needs them: a tuple is integrated as one concatenated vector, decreasing t as (t -> -t, f -> -f)."""
     options = dict(options or {})
@@ -210,8 +210,12 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None):
         def flat_f(tau, v):
             return torch.cat([o.reshape(-1) for o in func(tau, unpack(v))])
 
+        # torchdiffeq's default norm for tuple states is the "mixed" norm: max over the components' RMS norms
+        def mixed(v):
+            return max(_rms(c) for c in torch.split(v, sizes))
+
         sol = odeint(flat_f, torch.cat([p.reshape(-1) for p in y0]), t, rtol=rtol, atol=atol, method=method,
-                     options=options)
+                     options=options, _norm=mixed)
         return tuple(c.view((len(t),) + tuple(s)) for c, s in zip(torch.split(sol, sizes, dim=1), shapes))
 
     t = t.to(y0.device)
@@ -223,7 +227,7 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None):
     if method in _FIXED:
         return fixed_grid_solve(func, y0, t.to(y0.dtype), method, step_size=options.get("step_size"))
     if method == "dopri5":
-        return dopri5_solve(func, y0, t, rtol=rtol, atol=atol)
+        return dopri5_solve(func, y0, t, rtol=rtol, atol=atol, norm=_norm or _rms)
     raise ValueError(f"oracle does not restate method {method!r}")
 
 

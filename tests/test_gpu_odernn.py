@@ -1,0 +1,99 @@
+"""GPU: the ODE-RNN motion latent (BASELINE.json configs[4]; models/mocogan_ode_rnn.py) -- kernels through the C ABI
+and the drop-in generator class against the CPU oracle (oracle.mocogan_ref.GeneratorOdeRnn on oracle.ode_ref's
+dopri5).  Parity is unpinned for this row (reference file un-importable, torchdiffeq absent, no fixture).
+Adaptive step sequences differ between two fp32 implementations, so states agree to the solver tolerance (~1e-6),
+asserted at 2e-5; gradients (fixed 32-substep adjoint vs the oracle's adaptive adjoint) at 5e-4."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, seed_all
+
+import gan_ode_amd as G
+import gan_ode_amd._lib as L
+from oracle import mocogan_ref as M
+from oracle import ode_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("N,T", [(20, 5), (32, 16), (300, 3)])
+def test_odernn_kernels_against_oracle(N, T):
+    torch.manual_seed(N)
+    f = M.OdeRhs(16, 16)
+    gru = torch.nn.GRUCell(16, 16)
+    noise = torch.randn(T + 1, N, 16)
+    # oracle
+    h = [noise[0]]
+    hps = []
+    t01 = torch.tensor([0.0, 1.0])
+    for t in range(T):
+        hp = ode_ref.odeint_adjoint(f, h[-1], t01)[-1]
+        hps.append(hp)
+        h.append(gru(noise[t + 1], hp))
+    zref = torch.stack(h[1:], dim=1)                       # [N, T, 16]
+    gup = torch.randn(N, T, 16, generator=torch.Generator().manual_seed(7))
+    (zref * gup).sum().backward()
+    ref_grads = [p.grad for p in list(f.parameters()) + [gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh]]
+    # device
+    P = [p.detach().cuda() for p in list(f.parameters()) + [gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh]]
+    op = L.OdeRnnParams(*[p.data_ptr() for p in P])
+    nz, content = noise.cuda(), torch.randn(N, 50).cuda()
+    z = torch.full((N * T, 72), float("nan"), device="cuda")
+    hp_d = torch.empty(N, T, 16, device="cuda")
+    nst = torch.zeros((N + 255) // 256 * T, dtype=torch.int32, device="cuda")
+    fop = L.OdeRnnFwdOp(p=op, noise=nz.data_ptr(), content=content.data_ptr(), sel_t=None, z=z.data_ptr(), hs=None,
+                        hp=hp_d.data_ptr(), nsteps=nst.data_ptr(), N=N, T=T, rtol=1e-7, atol=1e-9)
+    L.run_one(fop, stream())
+    zz = z.cpu().view(N, T, 72)
+    assert rel_err(hp_d.cpu(), torch.stack(hps, dim=1).detach()) < 2e-5
+    assert rel_err(zz[:, :, :16], zref.detach()) < 2e-5
+    assert torch.equal(zz[:, :, 16:66], content.cpu()[:, None, :].expand(N, T, 50)) and float(zz[:, :, 66:].abs().max()) == 0
+    steps = nst.cpu()
+    assert int(steps.min()) >= 2 and int(steps.max()) < 200, steps      # the controller converges in a handful of steps
+    gz = torch.zeros(N * T, 72, device="cuda")
+    gz.view(N, T, 72)[:, :, :16] = gup.cuda()
+    grads = torch.full((L.ODERNN_NPARAM,), float("nan"), device="cuda")
+    work = torch.empty(L.lib().gode_odernn_bwd_work_size(N), device="cuda")
+    bop = L.OdeRnnBwdOp(p=op, noise=nz.data_ptr(), hp=hp_d.data_ptr(), sel_t=None, gz=gz.data_ptr(), work=work.data_ptr(),
+                        grads=grads.data_ptr(), N=N, T=T, substeps=32, accumulate=0)
+    L.run_one(bop, stream())
+    g = grads.cpu()
+    off = 0
+    for name, r in zip(("W1", "b1", "W2", "b2", "Wih", "Whh", "bih", "bhh"), ref_grads):
+        n = r.numel()
+        assert rel_err(g[off:off + n].view_as(r), r) < 5e-4, name
+        off += n
+
+
+def test_odernn_generator_against_oracle():
+    seed_all(5)
+    gen = G.VideoGeneratorMNISTODERNN(1, 50, 0, 16, 16, ngf=8)
+    ref = M.GeneratorOdeRnn(1, 50, 0, 16, 16, ngf=8, mnist=True)
+    ref.load_state_dict(gen.state_dict())
+    gen.cuda()
+    seed_all(6)
+    vid, labels = gen.sample_videos(4)
+    img, _ = gen.sample_images(4)
+    seed_all(6)
+    rvid, _ = ref.sample_videos(4)
+    rimg, _ = ref.sample_images(4)
+    assert vid.shape == (4, 1, 16, 28, 28) and img.shape == (4, 1, 28, 28)
+    assert rel_err(vid.detach().cpu(), rvid.detach()) < 1e-4
+    assert rel_err(img.detach().cpu(), rimg.detach()) < 1e-4
+    wv = torch.randn(vid.shape, generator=torch.Generator().manual_seed(1))
+    wi = torch.randn(img.shape, generator=torch.Generator().manual_seed(2))
+    ((vid * wv.cuda()).sum() + (img * wi.cuda()).sum()).backward()
+    ((rvid * wv).sum() + (rimg * wi).sum()).backward()
+    for (k, p), (_, q) in zip(gen.named_parameters(), ref.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None, k          # the pre-net `linear` is unused by the ODE-RNN variant
+        else:
+            d = (p.grad.cpu() - q.grad).abs()
+            assert float(d.median() / (q.grad.norm() / q.grad.numel() ** 0.5)) < 5e-3, k
+            assert rel_err(p.grad.cpu(), q.grad) < 5e-2, k
+    assert gen.recurrent.weight_hh.grad is not None       # the GRU cell is live in this variant

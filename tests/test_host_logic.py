@@ -172,3 +172,22 @@ def test_rot_mnist_reader_and_device_streams(tmp_path):
         seen += [int(np.where((X[:30] == v[i].numpy().reshape(16, 784)).all(axis=(1, 2)))[0][0]) for i in range(8)]
     assert len(set(seen)) == 24              # no clip repeats inside an epoch
     assert next(ims).shape == (8, 1, 28, 28)
+
+
+def test_odernn_dropin_constructs_and_draws_like_the_oracle():
+    """models/mocogan_ode_rnn.py drop-in: same state_dict keys as the restated reference class, host noise drawn in
+    the reference order (NumPy content, then h_0 and one e_t per frame from FloatTensor.normal_), no CPU path."""
+    from models.mocogan_ode_rnn import VideoGeneratorMNISTODERNN
+    seed_all(3)
+    gen = VideoGeneratorMNISTODERNN(1, 50, 0, 16, 16, ngf=8)
+    ref = M.GeneratorOdeRnn(1, 50, 0, 16, 16, ngf=8, mnist=True)
+    assert list(gen.state_dict().keys()) == list(ref.state_dict().keys())
+    seed_all(5)
+    content, noise = gen._draw(4, 16)
+    seed_all(5)
+    oc = ref.sample_z_content(4)
+    h0, e0 = ref._normal(4), ref._normal(4)
+    assert noise.shape == (17, 4, 16) and torch.equal(noise[0], h0) and torch.equal(noise[1], e0)
+    assert torch.equal(oc[::16], content)
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        gen.sample_videos(2)
