@@ -96,10 +96,12 @@ def _kernel_roofline(gen, reps=30):
     return roof
 
 
-def _cpu_baseline(budget_s=15.0):
+def _cpu_baseline(budget_s=15.0, threads=None):
     """The oracle (CPU port of the reference path on stock torch kernels) timed on the host cores: same workload,
     bounded sample."""
     from oracle import mocogan_ref as M
+    if threads:
+        torch.set_num_threads(threads)
     torch.manual_seed(0); np.random.seed(0)
     gen, _, _ = M.build_mnist()
     with torch.no_grad():
@@ -113,7 +115,7 @@ def _cpu_baseline(budget_s=15.0):
                 break
     return {"value": round(n * B / el, 2), "unit": "videos/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} calls of oracle sample_videos({B}) (ngf=64, T=16, train-mode BN, no_grad) in {el:.1f}s, "
-                      f"os.cpu_count()={os.cpu_count()}"}
+                      f"os.cpu_count()={os.cpu_count()}, cgroup CPU quota={threads}"}
 
 
 def main():
@@ -123,6 +125,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--train-steps", type=int, default=10, help="iterations for the G/D step timings")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="mnist", choices=["mnist", "ucf", "odernn"],
+                    help="mnist = BASELINE configs[1] (default, the headline); ucf = configs[3] shapes (batch 16, "
+                         "3x64x64, rk4 as the code does); odernn = configs[4] (ODE-RNN latent, batch 32)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,8 +143,18 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import gan_ode_amd as G
+    global B
+    quota = G.limit_host_threads()     # size torch's CPU pool to the cgroup quota (see its docstring)
     torch.manual_seed(1234 + rank); np.random.seed(1234 + rank)
-    gen, dv, di = G.build_mnist()
+    C_, HW = 1, 28
+    if a.config == "ucf":
+        gen, dv, di = G.build_ucf()
+        B, C_, HW = 16, 3, 64
+    elif a.config == "odernn":
+        gen, dv, di = G.build_mnist()
+        gen = G.VideoGeneratorMNISTODERNN(1, 50, 0, 16, 16)
+    else:
+        gen, dv, di = G.build_mnist()
     gen.cuda(); dv.cuda(); di.cuda()
     if distributed:   # replicas start from rank 0's weights
         for m in (gen, dv, di):
@@ -156,8 +171,8 @@ def main():
     # G / D step and whole-iteration milliseconds (synthetic real data resident on the GPU)
     tr = G.GanTrainer(gen, dv, di)
     g = torch.Generator().manual_seed(99 + rank)
-    imgs = [torch.rand(B, 1, 28, 28, generator=g).cuda() for _ in range(2)]
-    vids = [torch.rand(B, T, 1, 28, 28, generator=g).cuda() for _ in range(2)]
+    imgs = [torch.rand(B, C_, HW, HW, generator=g).cuda() for _ in range(2)]
+    vids = [torch.rand(B, T, C_, HW, HW, generator=g).cuda() for _ in range(2)]
     k = max(1, a.train_steps)
     wtr = max(1, min(3, k))
     d_ms = _timed(lambda: (tr.d_image_step(imgs[0]), tr.d_video_step(vids[0])), k, wtr, distributed) / k * 1e3
@@ -165,16 +180,20 @@ def main():
     it_ms = _timed(lambda: tr.step(imgs, vids), k, 1, distributed) / k * 1e3
 
     if rank == 0:
-        roof = _kernel_roofline(gen)
-        cpu = None if a.no_cpu_baseline or distributed else _cpu_baseline()
+        roof = _kernel_roofline(gen) if a.config == "mnist" else None
+        cpu = None if a.no_cpu_baseline or distributed or a.config != "mnist" else _cpu_baseline(threads=quota)
+        workload = {"mnist": "Rotated-MNIST MoCoGAN+ODE, gen.sample_videos(32): batch 32/GPU, 16x1x28x28, ngf=ndf=64, "
+                             "rk4 (Kutta 3/8) on linspace(0,1,16) = 15 steps as the reference code does, train-mode BN, "
+                             "random-init weights",
+                    "ucf": "UCF101-shaped MoCoGAN+ODE, gen.sample_videos(16): batch 16/GPU, 16x3x64x64, ngf=ndf=64, "
+                           "rk4 as the reference code does, dim_hidden=16",
+                    "odernn": "Rotated-MNIST MoCoGAN+ODE-RNN, gen.sample_videos(32): batch 32/GPU, dopri5 (1e-7/1e-9) "
+                              "+ GRUCell per frame"}[a.config]
         line = {
             "metric": "generated videos/sec (16-frame clips)", "value": round(vps, 2), "unit": "videos/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Rotated-MNIST MoCoGAN+ODE, gen.sample_videos(32): batch 32/GPU, 16x1x28x28, "
-                                   "ngf=ndf=64, rk4 (Kutta 3/8) on linspace(0,1,16) = 15 steps as the reference code "
-                                   "does, train-mode BN, random-init weights",
-                       "global_batch": world * B, "parallelism": f"dp{world}"},
+            "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}"},
             "d_step_ms": round(d_ms, 3), "g_step_ms": round(g_ms, 3), "iteration_ms": round(it_ms, 3),
             "train_videos_per_s": round(world * B / (it_ms / 1e3), 2),
             "roofline": roof, "cpu_baseline": cpu,

@@ -7,8 +7,16 @@ anything does, and there is no fallback path.
 from . import _lib
 from .modules import (Noise, ODEFunc, PatchImageDiscriminator, VideoDiscriminator, VideoGenerator,
                       VideoGeneratorMNIST, VideoGeneratorMNISTODE, VideoGeneratorMNISTODERNN)
-from .train import FusedAdam, GanTrainer, bce_with_logits_const, build_mnist, build_ucf, train_step
+from .train import (FusedAdam, GanTrainer, bce_with_logits_const, build_mnist, build_ucf, host_cpu_quota,
+                    limit_host_threads, train_step)
 
 __all__ = ["Noise", "ODEFunc", "PatchImageDiscriminator", "VideoDiscriminator", "VideoGenerator",
            "VideoGeneratorMNIST", "VideoGeneratorMNISTODE", "VideoGeneratorMNISTODERNN", "FusedAdam", "GanTrainer", "bce_with_logits_const",
-           "build_mnist", "build_ucf", "train_step", "_lib"]
+           "build_mnist", "build_ucf", "train_step", "host_cpu_quota", "limit_host_threads", "_lib"]
+
+import os as _os
+
+if _os.environ.get("GODE_KEEP_TORCH_THREADS") != "1":
+    # see train.limit_host_threads: an intra-op pool larger than the container's CPU quota gets the whole process
+    # throttled (75-90 ms stalls); opt out with GODE_KEEP_TORCH_THREADS=1
+    limit_host_threads()

@@ -4,7 +4,8 @@
 //
 // Forward: one launch for all T frames.  dopri5 with torchdiffeq's controller (initial step selection, accept iff
 // RMS(err/tol) <= 1, factor clipping 0.2..10, safety 0.9, 4th-order dense output at t = 1), the error norm taken
-// JOINTLY over all trajectories of the workgroup (up to 256) as torchdiffeq takes it over the batch.  Every 16x16
+// JOINTLY over all trajectories of the workgroup (up to 64; torchdiffeq takes it over the whole batch, which is the
+// same thing at the reference batch of 32).  Every 16x16
 // product (ODEFunc and the six GRU gate products) is a chained v_mfma_f32_16x16x4_f32 tile as in ode.hip.
 // Backward: GRU backward + continuous adjoint of each unit-interval solve.  torchdiffeq integrates the adjoint
 // adaptively to the same 1e-7 tolerance; here it is integrated with `substeps` fixed reverse-time Kutta-3/8 steps
@@ -12,6 +13,9 @@
 // HOW the same continuous adjoint is discretised, not in what is computed.
 #include "ode_common.h"
 
+// trajectories per workgroup of the forward kernel (4 waves): keeps the kernel inside the register file -- a spilling
+// build needed scratch memory, whose (re)allocation by the runtime stalled the queue for ~75 ms at a time
+#define RNN_BLOCK_SAMPLES 64
 #define RNN_NPARAM 2176
 #define RO_W1 0
 #define RO_B1 256
@@ -38,14 +42,14 @@ __device__ __forceinline__ f32x4 max4(const f32x4 a, const f32x4 b) {
   return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])};
 }
 
-__global__ void __launch_bounds__(1024) odernn_fwd_kernel(const gode_odernn_fwd_op a) {
-  __shared__ float red[16];
+__global__ void __launch_bounds__(RNN_BLOCK_SAMPLES * 4) odernn_fwd_kernel(const gode_odernn_fwd_op a) {
+  __shared__ float red[RNN_BLOCK_SAMPLES / 16];
   const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int s = l & 15, g = l >> 4;
-  const int n = blockIdx.x * 256 + wv * 16 + s;
+  const int n = blockIdx.x * RNN_BLOCK_SAMPLES + wv * 16 + s;
   const bool valid = n < a.N;
   const int T = a.T;
-  const int nblk = (a.N - blockIdx.x * 256) < 256 ? (a.N - blockIdx.x * 256) : 256;
+  const int nblk = (a.N - blockIdx.x * RNN_BLOCK_SAMPLES) < RNN_BLOCK_SAMPLES ? (a.N - blockIdx.x * RNN_BLOCK_SAMPLES) : RNN_BLOCK_SAMPLES;
   const float inv_count = 1.f / (float)(nblk * 16);
 
   const f32x4 w1 = ld4(a.p.W1 + s * 16 + 4 * g), w2 = ld4(a.p.W2 + s * 16 + 4 * g);
@@ -65,8 +69,10 @@ __global__ void __launch_bounds__(1024) odernn_fwd_kernel(const gode_odernn_fwd_
 
   for (int t = 0; t < T; ++t) {
     // ---- h' = y(1), y' = f(y), y(0) = h : dopri5 with torchdiffeq's controller
+    // the clock and the step size are kept in fp64 (as torchdiffeq keeps them): near the tolerance floor dt can
+    // shrink below the fp32 spacing of t, and an fp32 clock would then stop advancing
     f32x4 y0 = h, f0 = f(h), yend = h;
-    float dt;
+    double dtd;
     {
       const f32x4 sc = a.atol + abs4(y0) * a.rtol;
       const float d0 = rms(y0 / sc), d1 = rms(f0 / sc);
@@ -74,11 +80,12 @@ __global__ void __launch_bounds__(1024) odernn_fwd_kernel(const gode_odernn_fwd_
       const f32x4 f1 = f(y0 + h0 * f0);
       const float d2 = rms((f1 - f0) / sc) / h0;
       const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
-      dt = fminf(100.f * h0, h1);
+      dtd = (double)fminf(100.f * h0, h1);
     }
-    float tcur = 0.f;
+    double tcur = 0.0;
     int steps = 0;
     for (; steps < 100000; ++steps) {
+      const float dt = (float)dtd;
       const f32x4 k1 = f0;
       const f32x4 k2 = f(y0 + dt * (0.2f * k1));
       const f32x4 k3 = f(y0 + dt * ((3.f / 40.f) * k1 + (9.f / 40.f) * k2));
@@ -97,7 +104,7 @@ __global__ void __launch_bounds__(1024) odernn_fwd_kernel(const gode_odernn_fwd_
       const float ratio = rms(err / tol);
       const bool accept = ratio <= 1.f;
       if (accept) {
-        if (tcur + dt >= 1.f) {   // dense output (4th-order fit through the mid-point) at t = 1
+        if (tcur + dtd >= 1.0) {   // dense output (4th-order fit through the mid-point) at t = 1
           const f32x4 ymid = y0 + dt * ((6025192743.f / 30085553152.f / 2.f) * k1 + (51252292925.f / 65400821598.f / 2.f) * k3 +
                                         (-2691868925.f / 45128329728.f / 2.f) * k4 + (187940372067.f / 1594534317056.f / 2.f) * k5 +
                                         (-1776094331.f / 19743644256.f / 2.f) * k6 + (11237099.f / 235043384.f / 2.f) * k7);
@@ -105,17 +112,17 @@ __global__ void __launch_bounds__(1024) odernn_fwd_kernel(const gode_odernn_fwd_
           const f32x4 cb = dt * (5.f * k1 - 3.f * k7) + 18.f * y0 + 14.f * y1 - 32.f * ymid;
           const f32x4 cc = dt * (k7 - 4.f * k1) - 11.f * y0 - 5.f * y1 + 16.f * ymid;
           const f32x4 cd = dt * k1;
-          const float x = (1.f - tcur) / dt;
+          const float x = (float)((1.0 - tcur) / dtd);
           yend = y0 + x * (cd + x * (cc + x * (cb + x * ca)));
           ++steps;
           break;
         }
-        tcur += dt; y0 = y1; f0 = k7;
+        tcur += dtd; y0 = y1; f0 = k7;
       }
       float fac;
       if (ratio == 0.f) fac = 10.f;
       else { fac = 0.9f * powf(ratio, -0.2f); fac = fminf(10.f, fmaxf(fac, ratio < 1.f ? 1.f : 0.2f)); }
-      dt *= fac;
+      dtd *= (double)fac;
     }
     if (a.nsteps && threadIdx.x == 0) a.nsteps[blockIdx.x * T + t] = steps;
     if (valid && a.hp) *reinterpret_cast<f32x4*>(a.hp + ((int64_t)n * T + t) * 16 + 4 * g) = yend;
@@ -157,8 +164,8 @@ extern "C" int gode_odernn_fwd(const gode_odernn_fwd_op* op, void* stream) {
     hipLaunchKernelGGL(latent_content_kernel, dim3(blocks), dim3(256), 0, st, op->content, op->z, op->N, rows_per);
     GODE_LAUNCH_CHECK();
   }
-  const int nblocks = (op->N + 255) / 256;
-  const int per = op->N < 256 ? op->N : 256;
+  const int nblocks = (op->N + RNN_BLOCK_SAMPLES - 1) / RNN_BLOCK_SAMPLES;
+  const int per = op->N < RNN_BLOCK_SAMPLES ? op->N : RNN_BLOCK_SAMPLES;
   const int threads = ((per + 15) / 16) * 64;     // every workgroup gets this many waves; trailing lanes are masked
   hipLaunchKernelGGL(odernn_fwd_kernel, dim3(nblocks), dim3(threads), 0, st, *op);
   GODE_LAUNCH_CHECK();

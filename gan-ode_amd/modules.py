@@ -368,7 +368,7 @@ class _RnnGenPlan(_GenPlan):
         f32 = dict(dtype=torch.float32, device=self.device)
         self.noise = torch.empty(T + 1, n_traj, 16, **f32)
         self.hp = torch.empty(n_traj, T, 16, **f32)
-        self.nsteps = torch.zeros((n_traj + 255) // 256 * T, dtype=torch.int32, device=self.device)
+        self.nsteps = torch.zeros((n_traj + 63) // 64 * T, dtype=torch.int32, device=self.device)
         self.rnn_work = torch.empty(L.lib().gode_odernn_bwd_work_size(n_traj), **f32)
         self._ring = [dict(x=torch.empty(T + 1, n_traj, 16).pin_memory(), c=torch.empty(n_traj, 50).pin_memory(),
                            s=torch.zeros(n_traj, dtype=torch.int32).pin_memory(), ev=None) for _ in range(4)]
@@ -433,8 +433,16 @@ class VideoGeneratorMNISTODERNN(VideoGeneratorMNIST):
         """content (NumPy) first, then h_0 and one e_t per frame from FloatTensor(...).normal_()
         (models/mocogan.py:252,297-301; mocogan_ode_rnn.py:44-47)."""
         content = np.random.normal(0, 1, (num_samples, self.dim_z_content)).astype(np.float32)
-        noise = torch.stack([torch.FloatTensor(num_samples, self.dim_z_motion).normal_() for _ in range(video_len + 1)])
-        return torch.from_numpy(content), noise
+        # filled in place into a reused host buffer: the draws consume the generator exactly like the reference's
+        # fresh FloatTensor(n, d).normal_() calls, without a ~1 MB malloc/free per call (large transient host
+        # allocations next to a live HIP context showed up as 75-90 ms stalls on the GPU box)
+        key = (num_samples, video_len)
+        buf = self.__dict__.setdefault("_noise_bufs", {}).get(key)
+        if buf is None:
+            buf = self._noise_bufs[key] = torch.empty(video_len + 1, num_samples, self.dim_z_motion)
+        for i in range(video_len + 1):
+            buf[i].normal_()
+        return torch.from_numpy(content), buf
 
     def sample_images(self, num_samples):
         T = self.video_length

@@ -17,6 +17,30 @@ from .engine import stream_ptr
 from .modules import PatchImageDiscriminator, VideoDiscriminator, VideoGenerator, VideoGeneratorMNISTODE
 
 
+def host_cpu_quota():
+    """CPUs this process may actually use: the cgroup CPU quota if there is one, else the affinity mask size."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def limit_host_threads(n=None):
+    """torch's intra-op pool defaults to one thread per visible core (128 on the MI355X host) while the container's
+    cgroup quota is 16 CPUs: the idle pool spin-waits after every parallel region, the quota is exhausted and the
+    whole process is throttled for the rest of the 100 ms period (seen as random 75-90 ms stalls in the host-side
+    noise draws).  Call this once at start-up (bench.py does) to size the pool to the quota."""
+    n = n or host_cpu_quota()
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    return n
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # loss
 # ------------------------------------------------------------------------------------------------------------------

@@ -154,9 +154,9 @@ int64_t gode_ode_bwd_work_size(int32_t N);
 
 /* ---- ODE-RNN motion latent (models/mocogan_ode_rnn.py:41-53) -------------------------------
  * per frame: h' = odeint_adjoint(ODEFunc, h, [0,1])[-1] with torchdiffeq's default dopri5 (rtol, atol; error norm
- * joint over the trajectories of a workgroup, <= 256), h = GRUCell(e_t, h').  noise[T+1][N][16] = h_0, e_0..e_{T-1}
+ * joint over the trajectories of a workgroup, <= 64), h = GRUCell(e_t, h').  noise[T+1][N][16] = h_0, e_0..e_{T-1}
  * drawn on the host.  z / content / sel_t as in gode_ode_fwd (row t = h_{t+1}).  hs[N][T+1][16], hp[N][T][16]
- * (post-ODE states) are kept for the backward; nsteps[ceil(N/256)][T] (nullable) counts dopri5 trial steps. */
+ * (post-ODE states) are kept for the backward; nsteps[ceil(N/64)][T] (nullable) counts dopri5 trial steps. */
 typedef struct gode_odernn_params {
   const float* W1; const float* b1; const float* W2; const float* b2;         /* ODEFunc */
   const float* Wih; const float* Whh; const float* bih; const float* bhh;     /* GRUCell(16,16): [48,16]x2, [48]x2 */

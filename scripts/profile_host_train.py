@@ -4,6 +4,7 @@ import cProfile, os, pstats, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import gan_ode_amd as G
+G.limit_host_threads()
 torch.manual_seed(0); np.random.seed(0)
 gen, dv, di = G.build_mnist(); gen.cuda(); dv.cuda(); di.cuda()
 tr = G.GanTrainer(gen, dv, di)

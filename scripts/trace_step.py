@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import gan_ode_amd as G
+G.limit_host_threads()
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "sample"
 torch.manual_seed(0); np.random.seed(0)

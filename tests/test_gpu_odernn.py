@@ -45,7 +45,7 @@ def test_odernn_kernels_against_oracle(N, T):
     nz, content = noise.cuda(), torch.randn(N, 50).cuda()
     z = torch.full((N * T, 72), float("nan"), device="cuda")
     hp_d = torch.empty(N, T, 16, device="cuda")
-    nst = torch.zeros((N + 255) // 256 * T, dtype=torch.int32, device="cuda")
+    nst = torch.zeros((N + 63) // 64 * T, dtype=torch.int32, device="cuda")
     fop = L.OdeRnnFwdOp(p=op, noise=nz.data_ptr(), content=content.data_ptr(), sel_t=None, z=z.data_ptr(), hs=None,
                         hp=hp_d.data_ptr(), nsteps=nst.data_ptr(), N=N, T=T, rtol=1e-7, atol=1e-9)
     L.run_one(fop, stream())
