@@ -414,6 +414,30 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* work, fl
   }
 }
 
+// few outputs, many slabs (thin path): 64 outputs x 4 slab lanes per workgroup, fixed-order combine through LDS
+__global__ void __launch_bounds__(256) wgrad_reduce_small_kernel(const float* work, float* dw, int Co, int Ci, int taps,
+                                                                 int splits, const int32_t* co_perm, int accumulate) {
+  __shared__ double red[4][64];
+  const int Kt = Ci * taps, total = Co * Kt;
+  const int o = threadIdx.x & 63, ln = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  double sd = 0.0;
+  if (i < total) {
+#pragma unroll 4
+    for (int zz = ln; zz < splits; zz += 4) sd += (double)work[(int64_t)zz * total + i];
+  }
+  red[ln][o] = sd;
+  __syncthreads();
+  if (ln == 0 && i < total) {
+    const float sv = (float)(red[0][o] + red[1][o] + red[2][o] + red[3][o]);
+    int co = i / Kt;
+    const int j = i - co * Kt, tap = j / Ci, ci = j - tap * Ci;
+    if (co_perm) { co = co_perm[co]; if (co < 0) return; }
+    float* dptr = dw + ((int64_t)co * Ci + ci) * taps + tap;
+    *dptr = accumulate ? *dptr + sv : sv;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 static int wg_tile(const gode_conv_geom& g) { return g.Co <= 32 ? 0 : (g.Co <= 64 ? 1 : 2); }
 static int wg_bi(int t) { return t == 0 ? 32 : (t == 1 ? 64 : 128); }
@@ -436,8 +460,8 @@ static bool wg_thin(const gode_conv_geom& g) {
 }
 static int wg_thin_blocks(const gode_conv_geom& g) {
   const int64_t M = (int64_t)g.N * g.Do * g.Ho * g.Wo;
-  int64_t b = (M + 1023) / 1024;
-  return (int)(b > 256 ? 256 : (b < 1 ? 1 : b));
+  int64_t b = (M + 255) / 256;     // 16 positions per thread: enough workgroups to cover the gather latency
+  return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
 }
 static int wg_splits(const gode_wgrad_op* op) {
   if (op->splits <= 0 && wg_thin(op->g)) return wg_thin_blocks(op->g);
@@ -501,6 +525,12 @@ extern "C" int gode_wgrad(const gode_wgrad_op* op, void* stream) {
   else rc = wg_launch<2, 2, 2, 2>(A, vx, vy, splits, st);
   if (rc) return rc;
   const int64_t total = (int64_t)g.Co * A.Kt;
+  if (total <= 8192 && splits >= 16) {
+    hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, st, op->work, op->dw, g.Co,
+                       g.Ci, A.taps, splits, op->co_perm, op->accumulate);
+    GODE_LAUNCH_CHECK();
+    return 0;
+  }
   const bool v4 = A.Kt % 4 == 0 && (uintptr_t)op->work % 16 == 0;
   int blocks = (int)((total / (v4 ? 4 : 1) + 255) / 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
   if (v4) hipLaunchKernelGGL((wgrad_reduce_kernel<true>), dim3(blocks), dim3(256), 0, st, op->work, op->dw, g.Co, g.Ci,

@@ -313,3 +313,36 @@ def test_unchanged_driver_surface_with_stock_adam_and_bce():
     assert all(p.grad is not None for p in disVid.parameters())
     sd = gen.state_dict()
     assert float((sd["main.0.weight"].cpu() - torch.from_numpy(g["w1/gen/main.0.weight"])).abs().median()) < 2e-6
+
+
+def test_reference_api_corner_cases():
+    """video_len other than the constructor's (models/mocogan.py:271-272), linear=False (nn.Identity pre-net),
+    eval-mode discriminator, and .squeeze() at batch 1 (models/mocogan.py:162 drops the batch dim too)."""
+    seed_all(31)
+    gen = G.VideoGeneratorMNISTODE(1, 50, 0, 16, 16, ngf=8, linear=False)
+    ref = M.Generator(1, 50, 0, 16, 16, ngf=8, mnist=True)
+    ref.linear = torch.nn.Identity()
+    ref.load_state_dict(gen.state_dict())
+    assert not any(k.startswith("linear") for k in gen.state_dict())
+    gen.cuda()
+    seed_all(32)
+    vid, _ = gen.sample_videos(3, video_len=8)
+    seed_all(32)
+    rvid, _ = ref.sample_videos(3, video_len=8)
+    assert vid.shape == (3, 1, 8, 28, 28) and rel_err(vid.detach().cpu(), rvid.detach()) < TOL
+    vid.sum().backward()
+    rvid.sum().backward()
+    assert robust_rel(gen.ode_fn.fn[0].weight.grad.cpu(), ref.ode_fn.fn[0].weight.grad) < 5e-3
+    dis, rdis = G.VideoDiscriminator(1, ksize=2, ndf=8), M.VideoDisc(1, ksize=2, ndf=8)
+    rdis.load_state_dict(dis.state_dict())
+    dis.cuda()
+    x = torch.rand(1, 1, 16, 28, 28, generator=torch.Generator().manual_seed(1))
+    out, _ = dis(x.cuda())
+    want, _ = rdis(x)
+    assert out.shape == want.shape == (11, 2, 2) and rel_err(out.detach().cpu(), want.detach()) < TOL
+    dis.eval(); rdis.eval()
+    x4 = torch.rand(4, 1, 16, 28, 28, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        out, _ = dis(x4.cuda())
+        want, _ = rdis(x4)
+    assert rel_err(out.cpu(), want) < TOL
