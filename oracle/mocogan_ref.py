@@ -71,7 +71,7 @@ class Generator(nn.Module):
 
     def _dtype(self):
         """fp32 as the reference; a .double() copy of the module gives an fp64 yardstick fed by the SAME fp32 draws."""
-        return self.linear[0].weight.dtype
+        return self.ode_fn.fn[0].weight.dtype
 
     # -- latent samplers; RNG call order is part of the contract (mocogan.py:249-269, mocogan_ode.py:133-148)
     def sample_z_content(self, n, video_len=None):
