@@ -27,6 +27,7 @@ struct IgemmArgs {
   int32_t gsN, gsD, gsH, gsW, gsC;
   int32_t act, epilogue;
   int32_t MB, NB, xcd_mode;   // FAST kernel: 1-D grid of MB*NB*nphase workgroups, decoded XCD-aware (see igemm_block_id)
+  int32_t stagger;                   // tuning knob: de-phase co-resident workgroups (units of s_sleep 64)
   int32_t ksplit, slabs_per_split;   // split-K: grid is ksplit copies of the above; partial tiles go to work
   float* work;
   int32_t out_numel;
@@ -282,6 +283,10 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
   igemm_block_id(a, mblk, nblk, phase, split);
   const PhaseGeom& P = a.G.ph[phase];
   if (mblk * BM >= P.M) return;
+  if (a.stagger > 0) {   // identical workgroups started together run in lockstep; offset them by quarters of a slab period
+    const int q = (blockIdx.x >> 8) & 3;
+    for (int i = 0; i < q * a.stagger; ++i) __builtin_amdgcn_s_sleep(64);
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int Cg = a.G.Cg, Ncols = a.G.Ncols;
@@ -682,6 +687,8 @@ static int launch(IgemmArgs& A, bool vec, int max_mblk, bool double_buf, const S
   if (fast) {
     const int MB = max_mblk, NB = (int)grid.y, NC = NB * A.G.nphase;
     A.MB = MB; A.NB = NB; A.xcd_mode = 0;
+    static const char* senv = getenv("GODE_IGEMM_STAGGER");
+    A.stagger = senv ? atoi(senv) : 0;
     static const char* xenv = getenv("GODE_IGEMM_XCD");
     const int force = xenv ? atoi(xenv) : -1;
     const int64_t wbytes = gode_pack_floats(A.G) * 4;
@@ -731,6 +738,7 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
   A.src = op->src; A.w = op->wpack; A.out = op->out; A.scale = op->scale; A.shift = op->shift; A.stats = op->stats;
   A.gsN = (int)gs[0]; A.gsD = (int)gs[1]; A.gsH = (int)gs[2]; A.gsW = (int)gs[3]; A.gsC = (int)gs[4];
   A.act = op->act; A.epilogue = op->epilogue;
+  A.stagger = 0;
   A.work = op->work; A.out_numel = (int32_t)outn; A.ksplit = 1; A.slabs_per_split = 0; A.MB = 0; A.NB = 0; A.xcd_mode = 0;
   if ((op->scale == nullptr) != (op->shift == nullptr)) return GODE_E_ARG;
   const bool vec = gs[4] == 1 && (G.Cg % 4) == 0 && (gs[0] % 4) == 0 && (gs[1] % 4) == 0 && (gs[2] % 4) == 0 &&

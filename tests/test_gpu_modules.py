@@ -346,3 +346,42 @@ def test_reference_api_corner_cases():
         out, _ = dis(x4.cuda())
         want, _ = rdis(x4)
     assert rel_err(out.cpu(), want) < TOL
+
+
+def test_full_width_train_iterations_batch8_against_oracle():
+    """BASELINE.json configs[0] (the reference's CPU-runnable case: batch 8, 16x1x28x28, ngf=ndf=64, rk4): two full
+    training iterations (2 x [image-D, video-D] + G each) with FusedAdam / fused BCE against the oracle's
+    train_step on stock torch.  Losses of every iteration at 1e-4 relative (iteration 1) / 1e-3 (iteration 2, which
+    already depends on updated weights), BatchNorm running statistics at 1e-3, eval-mode samples at 1e-2."""
+    seed_all(41)
+    gen, dv, di = G.build_mnist()
+    ogen, odv, odi = M.build_mnist()
+    for m, o in zip((gen, dv, di), (ogen, odv, odi)):
+        o.load_state_dict(m.state_dict())
+    gen.cuda(); dv.cuda(); di.cuda()
+    tr = G.GanTrainer(gen, dv, di)
+    opts = M.make_optimizers(ogen, odv, odi)
+    B = 8
+    g = torch.Generator().manual_seed(5)
+    for it in range(2):
+        imgs = [torch.rand(B, 1, 28, 28, generator=g) for _ in range(2)]
+        vids = [torch.rand(B, 16, 1, 28, 28, generator=g) for _ in range(2)]
+        seed_all(100 + it)
+        got = [float(v) for v in G.train_step(tr, [t.cuda() for t in imgs], [t.cuda() for t in vids])]
+        seed_all(100 + it)
+        want = [float(v) for v in M.train_step(ogen, odv, odi, opts, imgs, vids)]
+        assert np.allclose(got, want, rtol=1e-4 if it == 0 else 1e-3, atol=0), (it, got, want)
+    for m, o in zip((gen, dv, di), (ogen, odv, odi)):
+        for (k, v), (_, w) in zip(m.state_dict().items(), o.state_dict().items()):
+            if "running_" in k:
+                assert rel_err(v.cpu(), w) < 1e-3, k
+            elif v.dtype == torch.int64:
+                assert int(v) == int(w), k
+    gen.eval(); ogen.eval()
+    seed_all(7)
+    with torch.no_grad():
+        ev, _ = gen.sample_videos(4)
+    seed_all(7)
+    with torch.no_grad():
+        rev, _ = ogen.sample_videos(4)
+    assert rel_err(ev.cpu(), rev) < 1e-2
