@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const IgemmArgs a) {
 // DB=true : two LDS buffers, one barrier per slab, staging interleaved with this wave's own MFMAs.
 // DB=false: one LDS buffer (half the LDS => twice the resident workgroups, 4 waves per SIMD), two barriers per slab;
 //           the staging of one workgroup is covered by the MFMAs of the three others on the SIMD.
-template <int WM, int WN, int TM, int TN, bool DB>
+template <int WM, int WN, int TM, int TN, bool DB, bool XF>
 __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs a) {
   constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32, LDK = 36;
   constexpr int RPP = NT / 8;
@@ -341,25 +341,32 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
   }
   f32x4 ra[AP], rb[BP], sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
   unsigned amask = 0;
+  int roff[AP];          // element offset of (row, current tap, channel 0); refreshed only when the tap changes
+  bool tap_dirty = true;
 
   auto fetch = [&](int slab) {
     const int c = c0 + kchunk;
-    if (xf) { sc4 = *reinterpret_cast<const f32x4*>(a.scale + c); sh4 = *reinterpret_cast<const f32x4*>(a.shift + c); }
-    amask = 0;
+    if (XF && xf) { sc4 = *reinterpret_cast<const f32x4*>(a.scale + c); sh4 = *reinterpret_cast<const f32x4*>(a.shift + c); }
+    if (tap_dirty) {     // wave-uniform: once per tap (every Cg/32 slabs), not per slab
+      amask = 0;
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      const int id = rbd[i] + J * jd, ih = rbh[i] + J * jh, iw = rbw[i] + J * jw;
-      const bool ok = rbase[i] >= 0 && (unsigned)id < (unsigned)Gd && (unsigned)ih < (unsigned)Gh && (unsigned)iw < (unsigned)Gw;
-      const int off = ok ? rbase[i] + id * a.gsD + ih * a.gsH + iw * a.gsW + c : 0;
-      ra[i] = *reinterpret_cast<const f32x4*>(a.src + off);
-      amask |= (ok ? 1u : 0u) << i;
+      for (int i = 0; i < AP; ++i) {
+        const int id = rbd[i] + J * jd, ih = rbh[i] + J * jh, iw = rbw[i] + J * jw;
+        const bool ok = rbase[i] >= 0 && (unsigned)id < (unsigned)Gd && (unsigned)ih < (unsigned)Gh && (unsigned)iw < (unsigned)Gw;
+        roff[i] = ok ? rbase[i] + id * a.gsD + ih * a.gsH + iw * a.gsW + kchunk : 0;
+        amask |= (ok ? 1u : 0u) << i;
+      }
+      tap_dirty = false;
     }
+#pragma unroll
+    for (int i = 0; i < AP; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a.src + roff[i] + (((amask >> i) & 1u) ? c0 : 0));
 #pragma unroll
     for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + slab * 32);
     // advance the odometer (uniform)
     c0 += 32;
     if (c0 >= Cg) {
       c0 = 0;
+      tap_dirty = true;
       if (++jw == P.Tw) { jw = 0; if (++jh == P.Th) { jh = 0; ++jd; } }
     }
   };
@@ -371,8 +378,8 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
       const bool ok = (amask >> i) & 1u;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float t = ra[i][e] * sc4[e] + sh4[e];
-        t = t > 0.f ? t : t * neg;
+        float t = ra[i][e];
+        if (XF) { t = t * sc4[e] + sh4[e]; t = fmaxf(t, t * neg); }   // neg in [0,1]: max(t, neg*t) == act(t)
         v[e] = ok ? t : 0.f;
       }
       *reinterpret_cast<f32x4*>(As + ((tid >> 3) + RPP * i) * LDK + kchunk) = v;
@@ -434,6 +441,19 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
     const int buf = (nslab - 1) & 1;
     mma_group(buf, 0); mma_group(buf, 1); mma_group(buf, 2); mma_group(buf, 3);
     __syncthreads();
+  } else if (a.stagger == -1) {        // ABLATION (timing only, wrong results): MFMA + LDS reads, no staging, no barriers
+    stageA(0); stageB(0);
+    __syncthreads();
+    for (int s = 0; s + 1 < nslab; ++s) { mma_group(0, 0); mma_group(0, 1); mma_group(0, 2); mma_group(0, 3); }
+  } else if (a.stagger == -2) {        // ABLATION: + barriers, still no staging
+    stageA(0); stageB(0);
+    __syncthreads();
+    for (int s = 0; s + 1 < nslab; ++s) { __syncthreads(); mma_group(0, 0); mma_group(0, 1); mma_group(0, 2); mma_group(0, 3); __syncthreads(); }
+  } else if (a.stagger == -3) {        // ABLATION: + global fetch, no LDS staging
+    stageA(0); stageB(0);
+    __syncthreads();
+    for (int s = 0; s + 1 < nslab; ++s) { __syncthreads(); fetch(s + 1); mma_group(0, 0); mma_group(0, 1); mma_group(0, 2); mma_group(0, 3); __syncthreads(); }
+    asm volatile("" :: "v"(ra[0][0]), "v"(rb[0][0]));
   } else {
     for (int s = 0; s + 1 < nslab; ++s) {
       stageA(0);
@@ -700,8 +720,14 @@ static int launch(IgemmArgs& A, bool vec, int max_mblk, bool double_buf, const S
     if (force == 2 && ok2) mode = 2;
     A.xcd_mode = mode;
     dim3 g1(MB * NC * sp.ksplit);
-    if (double_buf) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, true>), g1, block, 0, st, A);
-    else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false>), g1, block, 0, st, A);
+    const bool has_xf = A.scale != nullptr || A.act != GODE_ACT_NONE;
+    if (double_buf) {
+      if (has_xf) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, true, true>), g1, block, 0, st, A);
+      else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, true, false>), g1, block, 0, st, A);
+    } else {
+      if (has_xf) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false, true>), g1, block, 0, st, A);
+      else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false, false>), g1, block, 0, st, A);
+    }
     if (sp.ksplit > 1) {
       GODE_LAUNCH_CHECK();
       hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(gode_ceil_div(sp.positions, SPLITK_ROWS)), dim3(256), 0, st, A.work, A.out,
