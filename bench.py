@@ -181,7 +181,7 @@ def main():
 
     if rank == 0:
         roof = _kernel_roofline(gen) if a.config == "mnist" else None
-        cpu = None if a.no_cpu_baseline or distributed or a.config != "mnist" else _cpu_baseline(threads=quota)
+        cpu = None if a.no_cpu_baseline or distributed or a.config != "mnist" else _cpu_baseline(threads=G.host_cpu_quota())
         workload = {"mnist": "Rotated-MNIST MoCoGAN+ODE, gen.sample_videos(32): batch 32/GPU, 16x1x28x28, ngf=ndf=64, "
                              "rk4 (Kutta 3/8) on linspace(0,1,16) = 15 steps as the reference code does, train-mode BN, "
                              "random-init weights",

@@ -17,6 +17,7 @@ extern "C" int gode_sizeof(int kind) {
     case GODE_OP_PACK: return (int)sizeof(gode_pack_op);
     case GODE_OP_ODERNN_FWD: return (int)sizeof(gode_odernn_fwd_op);
     case GODE_OP_ODERNN_BWD: return (int)sizeof(gode_odernn_bwd_op);
+    case GODE_OP_BN_APPLY: return (int)sizeof(gode_bn_apply_op);
   }
   return GODE_E_KIND;
 }
@@ -38,6 +39,7 @@ extern "C" int gode_run(const int32_t* kinds, const void* const* ops, int32_t n,
       case GODE_OP_ADAM: rc = gode_adam_l2((const gode_adam_op*)ops[i], stream); break;
       case GODE_OP_ODERNN_FWD: rc = gode_odernn_fwd((const gode_odernn_fwd_op*)ops[i], stream); break;
       case GODE_OP_ODERNN_BWD: rc = gode_odernn_bwd((const gode_odernn_bwd_op*)ops[i], stream); break;
+      case GODE_OP_BN_APPLY: rc = gode_bn_apply((const gode_bn_apply_op*)ops[i], stream); break;
       case GODE_OP_PACK: {
         const gode_pack_op* p = (const gode_pack_op*)ops[i];
         rc = gode_pack_weights(&p->g, p->dir, p->w, p->wpack, p->co_perm, p->co_canon, stream);

@@ -62,6 +62,29 @@ extern "C" int gode_bn_finalize(const gode_bn_finalize_op* op, void* stream) {
   return 0;
 }
 
+__global__ void __launch_bounds__(256) bn_apply_kernel(const gode_bn_apply_op a) {
+  const int64_t n4 = a.M * a.C / 4;
+  const float neg = a.act == GODE_ACT_RELU ? 0.f : (a.act == GODE_ACT_LRELU ? 0.2f : 1.f);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)((i * 4) % a.C);
+    f32x4 v = *reinterpret_cast<const f32x4*>(a.y + i * 4);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (a.scale) { sc = *reinterpret_cast<const f32x4*>(a.scale + c); sh = *reinterpret_cast<const f32x4*>(a.shift + c); }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float t = v[e] * sc[e] + sh[e]; v[e] = fmaxf(t, t * neg); }
+    *reinterpret_cast<f32x4*>(a.out + i * 4) = v;
+  }
+}
+
+extern "C" int gode_bn_apply(const gode_bn_apply_op* op, void* stream) {
+  if (!op || !op->y || !op->out || op->M <= 0 || op->C <= 0 || op->C % 4 != 0) return GODE_E_ARG;
+  if ((op->scale == nullptr) != (op->shift == nullptr)) return GODE_E_ARG;
+  int64_t b = (op->M * op->C / 4 + 255) / 256;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((int)(b > 8192 ? 8192 : (b < 1 ? 1 : b))), dim3(256), 0, (hipStream_t)stream, *op);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // BatchNorm + activation backward
 #define BNB_ROWS 256   // rows per reduction block

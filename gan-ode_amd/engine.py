@@ -95,6 +95,8 @@ class ConvStack:
         self.x_in = torch.zeros(specs[0].in_dims(), **f32) if owns_input else None
         # raw outputs of all but the last layer are plan-owned; the last is allocated per call
         self.y = [torch.empty(s.out_dims(), **f32) for s in specs[:-1]]
+        # activated copies a[l] = act(BN(y[l])) for layers whose consumer is a heavy GEMM (see gode_bn_apply)
+        self.a = [torch.empty(s.out_dims(), **f32) if self._materialize(l) else None for l, s in enumerate(specs[:-1])]
         self.out_dims = specs[-1].out_dims()
         self.wpack_f, self.wpack_b = [], [None] * self.nl
         self.stats, self.stat_rows = [], []
@@ -167,9 +169,26 @@ class ConvStack:
                  g.Di == g.kd and g.Hi == g.kh and g.Wi == g.kw and g.kd * g.kh * g.kw > 1)
         return g.kd * g.kh * g.kw * g.Ci if fullk else g.Ci
 
-    def _in_xform(self, l):
-        """(scale, shift, act) the consumer of layer l-1's raw output applies."""
+    def _materialize(self, l):
+        """Materialise act(BN(y[l])) when the consuming layer l+1 is a heavy vector-path GEMM."""
+        if l + 1 >= len(self.specs):
+            return False
+        prod, cons = self.specs[l], self.specs[l + 1]
+        C_out = prod.out_dims()[4]
+        g = cons.geom
+        taps = g.kd * g.kh * g.kw
+        macs = g.N * g.Do * g.Ho * g.Wo * g.Co * g.Ci * taps
+        return C_out % 32 == 0 and macs >= (1 << 30) and (prod.has_bn or prod.act != L.ACT_NONE)
+
+    def _in_src(self, l):
+        """Tensor the consumer layer l reads (activated copy if materialised, else the raw producer output)."""
         if l == 0:
+            return self.x_in
+        return self.a[l - 1] if self.a[l - 1] is not None else self.y[l - 1]
+
+    def _in_xform(self, l):
+        """(scale, shift, act) the consumer of layer l-1's output applies on load."""
+        if l == 0 or self.a[l - 1] is not None:
             return None, None, L.ACT_NONE
         s = self.specs[l - 1]
         return (self.scale[l - 1], self.shift[l - 1], s.act) if s.has_bn else (None, None, s.act)
@@ -206,7 +225,7 @@ class ConvStack:
             packs.append((l, s.fwd_dir, L.PackOp(g=s.geom, dir=s.fwd_dir, co_canon=0, w=dptr(p.weight),
                                                  wpack=dptr(self.wpack_f[l]), co_perm=dptr(s.co_perm))))
             sc, sh, act = self._in_xform(l)
-            src = self.x_in if l == 0 else self.y[l - 1]
+            src = self._in_src(l)
             op = L.IgemmOp(g=s.geom, dir=s.fwd_dir, act=act, epilogue=s.epilogue, tile=0, src=dptr(src),
                            wpack=dptr(self.wpack_f[l]), out=dptr(self.y[l]) if l < self.nl - 1 else None,
                            scale=dptr(sc), shift=dptr(sh),
@@ -225,6 +244,10 @@ class ConvStack:
                                           invstd=dptr(self.invstd[l]), scale=dptr(self.scale[l]),
                                           shift=dptr(self.shift[l]), momentum=self.momentum, eps=self.eps,
                                           training=1 if training else 0))
+            if l < self.nl - 1 and self.a[l] is not None:
+                d = s.out_dims()
+                ops.append(L.BnApplyOp(y=dptr(self.y[l]), out=dptr(self.a[l]), scale=dptr(self.scale[l]),
+                                       shift=dptr(self.shift[l]), M=d[0] * d[1] * d[2] * d[3], C=d[4], act=s.act))
         patch["packs"] = packs
         self._attach_work([op for op in ops if isinstance(op, L.IgemmOp)])
         return L.Program(ops), patch
@@ -281,7 +304,7 @@ class ConvStack:
             s, p = self.specs[l], self.params[l]
             rev = L.DGRAD if s.fwd_dir == L.FPROP else L.FPROP
             sc, sh, act = self._in_xform(l)
-            src = self.x_in if l == 0 else self.y[l - 1]
+            src = self._in_src(l)
             # weight gradient
             if s.fwd_dir == L.FPROP:
                 w = L.WgradOp(g=s.geom, act=act, xform_on_y=0, splits=0, accumulate=0, x=dptr(src), y=dptr(self.g[l]),

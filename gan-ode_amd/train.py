@@ -35,7 +35,11 @@ def limit_host_threads(n=None):
     cgroup quota is 16 CPUs: the idle pool spin-waits after every parallel region, the quota is exhausted and the
     whole process is throttled for the rest of the 100 ms period (seen as random 75-90 ms stalls in the host-side
     noise draws).  Call this once at start-up (bench.py does) to size the pool to the quota."""
-    n = n or host_cpu_quota()
+    if n is None:
+        import os
+        # one process per GPU: the quota is shared by the ranks of this node
+        local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+        n = max(1, min(16, host_cpu_quota() // max(1, local)))
     if torch.get_num_threads() > n:
         torch.set_num_threads(n)
     return n

@@ -108,6 +108,14 @@ typedef struct gode_bn_finalize_op {
 } gode_bn_finalize_op;
 int gode_bn_finalize(const gode_bn_finalize_op* op, void* stream);
 
+/* out = act(y*scale[c] + shift[c]) over [M][C] (C % 4 == 0): materialises an activated tensor for consumers that are
+ * MFMA-bound and re-read every element several times (the heavy GEMMs run ~10-20 % faster without the transform
+ * in their operand path; light layers keep it fused).  scale==NULL: plain activation. */
+typedef struct gode_bn_apply_op {
+  const float* y; float* out; const float* scale; const float* shift; int64_t M; int32_t C, act;
+} gode_bn_apply_op;
+int gode_bn_apply(const gode_bn_apply_op* op, void* stream);
+
 /* backward of y -> BN -> act given g_a = dL/d(act output), all [M][C] channels-last:
  *   g_z = g_a * act'(scale*y+shift);  dbeta = sum g_z;  dgamma = sum g_z*xhat;
  *   g_y = gamma*invstd*(g_z - dbeta/M - xhat*dgamma/M)     written in place over g_a.
@@ -204,7 +212,7 @@ int gode_scale(float* out, const float* a, int64_t n, float alpha, int accumulat
 /* ---- program runner: executes n ops back to back on the stream (one host call per network pass) -------------*/
 enum { GODE_OP_IGEMM = 1, GODE_OP_WGRAD = 2, GODE_OP_BN_FINALIZE = 3, GODE_OP_BN_BWD = 4, GODE_OP_ODE_FWD = 5,
        GODE_OP_ODE_BWD = 6, GODE_OP_BCE = 7, GODE_OP_ADAM = 8, GODE_OP_PACK = 9, GODE_OP_ODERNN_FWD = 10,
-       GODE_OP_ODERNN_BWD = 11 };
+       GODE_OP_ODERNN_BWD = 11, GODE_OP_BN_APPLY = 12 };
 typedef struct gode_pack_op {
   gode_conv_geom g; int32_t dir, co_canon; const float* w; float* wpack; const int32_t* co_perm;
 } gode_pack_op;
