@@ -61,14 +61,14 @@ class OdeParams(C.Structure):
 
 class OdeFwdOp(C.Structure):
     _fields_ = [("p", OdeParams), ("x", ptr), ("content", ptr), ("dt", ptr), ("sel_t", ptr), ("z", ptr),
-                ("traj", ptr), ("N", i32), ("T", i32), ("substeps", i32), ("prenet", i32)]
+                ("traj", ptr), ("N", i32), ("T", i32), ("substeps", i32), ("prenet", i32), ("zcols", i32), ("pad_", i32)]
     KIND = OP_ODE_FWD
 
 
 class OdeBwdOp(C.Structure):
     _fields_ = [("p", OdeParams), ("x", ptr), ("traj", ptr), ("dt", ptr), ("sel_t", ptr), ("gz", ptr),
                 ("work", ptr), ("grads", ptr), ("N", i32), ("T", i32), ("substeps", i32), ("prenet", i32),
-                ("accumulate", i32), ("pad_", i32)]
+                ("accumulate", i32), ("zcols", i32)]
     KIND = OP_ODE_BWD
 
 
@@ -78,13 +78,15 @@ class OdeRnnParams(C.Structure):
 
 class OdeRnnFwdOp(C.Structure):
     _fields_ = [("p", OdeRnnParams), ("noise", ptr), ("content", ptr), ("sel_t", ptr), ("z", ptr), ("hs", ptr),
-                ("hp", ptr), ("nsteps", ptr), ("N", i32), ("T", i32), ("rtol", f32), ("atol", f32)]
+                ("hp", ptr), ("nsteps", ptr), ("N", i32), ("T", i32), ("rtol", f32), ("atol", f32), ("zcols", i32),
+                ("pad_", i32)]
     KIND = OP_ODERNN_FWD
 
 
 class OdeRnnBwdOp(C.Structure):
     _fields_ = [("p", OdeRnnParams), ("noise", ptr), ("hp", ptr), ("sel_t", ptr), ("gz", ptr), ("work", ptr),
-                ("grads", ptr), ("N", i32), ("T", i32), ("substeps", i32), ("accumulate", i32)]
+                ("grads", ptr), ("N", i32), ("T", i32), ("substeps", i32), ("accumulate", i32), ("zcols", i32),
+                ("pad_", i32)]
     KIND = OP_ODERNN_BWD
 
 

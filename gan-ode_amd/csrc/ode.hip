@@ -33,13 +33,14 @@ __global__ void __launch_bounds__(64) ode_fwd_kernel(const gode_ode_fwd_op a) {
     }
     __syncthreads();
     const int rows_per = a.sel_t ? 1 : T;
-    const int total4 = 16 * rows_per * 14;
+    const int q4 = (a.zcols - 16) >> 2;      // float4 chunks of content + pad per latent row
+    const int total4 = 16 * rows_per * q4;
     for (int i = l; i < total4; i += 64) {
-      const int rr = i / 14, q = i - rr * 14;
+      const int rr = i / q4, q = i - rr * q4;
       const int ns = rr / rows_per, tt = rr - ns * rows_per;
       if (n0 + ns < a.N) {
         const f32x4 v = q < 13 ? *reinterpret_cast<const f32x4*>(&cbuf[ns][4 * q]) : zero4();
-        *reinterpret_cast<f32x4*>(a.z + ((int64_t)(n0 + ns) * rows_per + tt) * 72 + 16 + 4 * q) = v;
+        *reinterpret_cast<f32x4*>(a.z + ((int64_t)(n0 + ns) * rows_per + tt) * a.zcols + 16 + 4 * q) = v;
       }
     }
   }
@@ -62,8 +63,8 @@ __global__ void __launch_bounds__(64) ode_fwd_kernel(const gode_ode_fwd_op a) {
   auto emit = [&](int t) {
     if (!valid) return;
     if (a.traj) *reinterpret_cast<f32x4*>(a.traj + ((int64_t)n * T + t) * 16 + 4 * g) = y;
-    if (a.sel_t == nullptr) *reinterpret_cast<f32x4*>(a.z + ((int64_t)n * T + t) * 72 + 4 * g) = y;
-    else if (t == tsel) *reinterpret_cast<f32x4*>(a.z + (int64_t)n * 72 + 4 * g) = y;
+    if (a.sel_t == nullptr) *reinterpret_cast<f32x4*>(a.z + ((int64_t)n * T + t) * a.zcols + 4 * g) = y;
+    else if (t == tsel) *reinterpret_cast<f32x4*>(a.z + (int64_t)n * a.zcols + 4 * g) = y;
   };
   emit(0);
   const float third = 1.0f / 3.0f;
@@ -83,6 +84,7 @@ __global__ void __launch_bounds__(64) ode_fwd_kernel(const gode_ode_fwd_op a) {
 
 extern "C" int gode_ode_fwd(const gode_ode_fwd_op* op, void* stream) {
   if (!op || !op->x || !op->z || !op->dt || op->N <= 0 || op->T < 1 || op->substeps < 1) return GODE_E_ARG;
+  if (op->zcols < 68 || op->zcols % 4 != 0) return GODE_E_ARG;
   if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2) return GODE_E_ARG;
   if (op->prenet && (!op->p.Wa || !op->p.ba || !op->p.Wb || !op->p.bb)) return GODE_E_ARG;
   hipLaunchKernelGGL(ode_fwd_kernel, dim3((op->N + 15) / 16), dim3(64), 0, (hipStream_t)stream, *op);
@@ -130,8 +132,8 @@ __global__ void __launch_bounds__(64) ode_bwd_kernel(const gode_ode_bwd_op a) {
   const int tsel = (a.sel_t && valid) ? a.sel_t[n] : -1;
   auto upstream = [&](int t) {
     if (!valid) return zero4();
-    if (a.sel_t == nullptr) return ld4(a.gz + ((int64_t)n * T + t) * 72 + 4 * g);
-    return t == tsel ? ld4(a.gz + (int64_t)n * 72 + 4 * g) : zero4();
+    if (a.sel_t == nullptr) return ld4(a.gz + ((int64_t)n * T + t) * a.zcols + 4 * g);
+    return t == tsel ? ld4(a.gz + (int64_t)n * a.zcols + 4 * g) : zero4();
   };
 
   f32x4 adj = upstream(T - 1);
@@ -229,6 +231,7 @@ extern "C" int64_t gode_ode_bwd_work_size(int32_t N) { return (int64_t)((N + 15)
 extern "C" int gode_ode_bwd(const gode_ode_bwd_op* op, void* stream) {
   if (!op || !op->traj || !op->gz || !op->dt || !op->work || !op->grads || op->N <= 0 || op->T < 1 || op->substeps < 1)
     return GODE_E_ARG;
+  if (op->zcols < 16 || op->zcols % 4 != 0) return GODE_E_ARG;
   if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2) return GODE_E_ARG;
   if (op->prenet && (!op->x || !op->p.Wa || !op->p.ba || !op->p.Wb || !op->p.bb)) return GODE_E_ARG;
   const int nblk = (op->N + 15) / 16;

@@ -134,34 +134,36 @@ __global__ void __launch_bounds__(RNN_BLOCK_SAMPLES * 4) odernn_fwd_kernel(const
     h = (1.f - zg) * nn + zg * yend;
     if (valid) {
       if (a.hs) *reinterpret_cast<f32x4*>(a.hs + ((int64_t)n * (T + 1) + t + 1) * 16 + 4 * g) = h;
-      if (a.sel_t == nullptr) *reinterpret_cast<f32x4*>(a.z + ((int64_t)n * T + t) * 72 + 4 * g) = h;
-      else if (t == tsel) *reinterpret_cast<f32x4*>(a.z + (int64_t)n * 72 + 4 * g) = h;
+      if (a.sel_t == nullptr) *reinterpret_cast<f32x4*>(a.z + ((int64_t)n * T + t) * a.zcols + 4 * g) = h;
+      else if (t == tsel) *reinterpret_cast<f32x4*>(a.z + (int64_t)n * a.zcols + 4 * g) = h;
     }
   }
 }
 
 // content columns 16..65 of the latent rows + zero pad (same layout as gode_ode_fwd writes)
-__global__ void __launch_bounds__(256) latent_content_kernel(const float* content, float* z, int N, int rows_per) {
-  const int64_t total4 = (int64_t)N * rows_per * 14;
+__global__ void __launch_bounds__(256) latent_content_kernel(const float* content, float* z, int N, int rows_per, int zcols) {
+  const int q4 = (zcols - 16) >> 2;
+  const int64_t total4 = (int64_t)N * rows_per * q4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-    const int64_t row = i / 14; const int q = (int)(i - row * 14);
+    const int64_t row = i / q4; const int q = (int)(i - row * q4);
     const int64_t nn = row / rows_per;
     f32x4 v = zero4();
     if (q < 12) v = f32x4{content[nn * 50 + 4 * q], content[nn * 50 + 4 * q + 1], content[nn * 50 + 4 * q + 2], content[nn * 50 + 4 * q + 3]};
     else if (q == 12) v = f32x4{content[nn * 50 + 48], content[nn * 50 + 49], 0.f, 0.f};
-    *reinterpret_cast<f32x4*>(z + row * 72 + 16 + 4 * q) = v;
+    *reinterpret_cast<f32x4*>(z + row * zcols + 16 + 4 * q) = v;
   }
 }
 
 extern "C" int gode_odernn_fwd(const gode_odernn_fwd_op* op, void* stream) {
   if (!op || !op->noise || !op->z || op->N <= 0 || op->T < 1 || !(op->rtol > 0.f) || !(op->atol >= 0.f)) return GODE_E_ARG;
+  if (op->zcols < 68 || op->zcols % 4 != 0) return GODE_E_ARG;
   if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2 || !op->p.Wih || !op->p.Whh || !op->p.bih || !op->p.bhh) return GODE_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (op->content) {
     const int rows_per = op->sel_t ? 1 : op->T;
-    int64_t total4 = (int64_t)op->N * rows_per * 14;
+    int64_t total4 = (int64_t)op->N * rows_per * ((op->zcols - 16) >> 2);
     int blocks = (int)((total4 + 255) / 256); if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(latent_content_kernel, dim3(blocks), dim3(256), 0, st, op->content, op->z, op->N, rows_per);
+    hipLaunchKernelGGL(latent_content_kernel, dim3(blocks), dim3(256), 0, st, op->content, op->z, op->N, rows_per, op->zcols);
     GODE_LAUNCH_CHECK();
   }
   const int nblocks = (op->N + RNN_BLOCK_SAMPLES - 1) / RNN_BLOCK_SAMPLES;
@@ -221,8 +223,8 @@ __global__ void __launch_bounds__(64) odernn_bwd_kernel(const gode_odernn_bwd_op
   const int tsel = (a.sel_t && valid) ? a.sel_t[n] : -1;
   auto upstream = [&](int t) {
     if (!valid) return zero4();
-    if (a.sel_t == nullptr) return ld4(a.gz + ((int64_t)n * T + t) * 72 + 4 * g);
-    return t == tsel ? ld4(a.gz + (int64_t)n * 72 + 4 * g) : zero4();
+    if (a.sel_t == nullptr) return ld4(a.gz + ((int64_t)n * T + t) * a.zcols + 4 * g);
+    return t == tsel ? ld4(a.gz + (int64_t)n * a.zcols + 4 * g) : zero4();
   };
   const float third = 1.0f / 3.0f, dt = 1.f / (float)a.substeps;
   f32x4 carry = zero4();
@@ -295,6 +297,7 @@ extern "C" int64_t gode_odernn_bwd_work_size(int32_t N) { return (int64_t)((N + 
 extern "C" int gode_odernn_bwd(const gode_odernn_bwd_op* op, void* stream) {
   if (!op || !op->noise || !op->hp || !op->gz || !op->work || !op->grads || op->N <= 0 || op->T < 1 || op->substeps < 1)
     return GODE_E_ARG;
+  if (op->zcols < 16 || op->zcols % 4 != 0) return GODE_E_ARG;
   if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2 || !op->p.Wih || !op->p.Whh || !op->p.bih || !op->p.bhh) return GODE_E_ARG;
   const int nblk = (op->N + 15) / 16;
   hipStream_t st = (hipStream_t)stream;

@@ -21,7 +21,7 @@ import torch.nn as nn
 from . import _lib as L
 from .engine import ConvStack, LayerParams, LayerSpec, conv_out, dptr, make_geom, stream_ptr
 
-Z_COLS = 72  # latent row: [motion 16 | content 50 | zero pad 6]
+Z_COLS = 96  # latent row: [motion 16 | content 50 | zero pad 30]: K % 32 == 0 puts the first decoder GEMM on the FAST path
 
 
 def _require_gpu(t: torch.Tensor, what: str):
@@ -117,10 +117,10 @@ class _GenPlan:
             prenet = 0 if ps[0] is None else 1
             self.fwd_op = L.OdeFwdOp(p=op, x=dptr(self.x), content=dptr(self.content), dt=dptr(self.dt),
                                      sel_t=dptr(self.sel), z=dptr(self.stack.x_in), traj=dptr(self.traj), N=self.n,
-                                     T=self.T, substeps=self.gen.ode_substeps, prenet=prenet)
+                                     T=self.T, substeps=self.gen.ode_substeps, prenet=prenet, zcols=Z_COLS)
             self.bwd_op = L.OdeBwdOp(p=op, x=dptr(self.x), traj=dptr(self.traj), dt=dptr(self.dt),
                                      sel_t=dptr(self.sel), gz=None, work=dptr(self.ode_work), grads=None, N=self.n,
-                                     T=self.T, substeps=self.gen.ode_substeps, prenet=prenet, accumulate=0)
+                                     T=self.T, substeps=self.gen.ode_substeps, prenet=prenet, accumulate=0, zcols=Z_COLS)
             self.fwd_prog = L.Program([self.fwd_op])
         self.fwd_op.substeps = self.bwd_op.substeps = self.gen.ode_substeps
 
@@ -239,7 +239,8 @@ class VideoGenerator(nn.Module):
     def _decoder_specs(self, rows):
         ngf, nc = self.ngf, self.n_channels
         dev = self.main[0].weight.device
-        perm = torch.tensor([50 + i for i in range(16)] + list(range(50)) + [-1] * 6, dtype=torch.int32, device=dev)
+        perm = torch.tensor([50 + i for i in range(16)] + list(range(50)) + [-1] * (Z_COLS - 66), dtype=torch.int32,
+                            device=dev)
         one = (1, 1, 1)
         specs = [LayerSpec(make_geom(rows, ngf * 8, Z_COLS, (1, 4, 4), one, (1, 4, 4), one, (0, 0, 0)), L.DGRAD,
                            L.ACT_RELU, True, co_perm=perm)]
@@ -386,10 +387,10 @@ class _RnnGenPlan(_GenPlan):
             op = L.OdeRnnParams(*ptrs)
             self.fwd_op = L.OdeRnnFwdOp(p=op, noise=dptr(self.noise), content=dptr(self.content), sel_t=dptr(self.sel),
                                         z=dptr(self.stack.x_in), hs=None, hp=dptr(self.hp), nsteps=dptr(self.nsteps),
-                                        N=self.n, T=self.T, rtol=self.gen.ode_rtol, atol=self.gen.ode_atol)
+                                        N=self.n, T=self.T, rtol=self.gen.ode_rtol, atol=self.gen.ode_atol, zcols=Z_COLS)
             self.bwd_op = L.OdeRnnBwdOp(p=op, noise=dptr(self.noise), hp=dptr(self.hp), sel_t=dptr(self.sel), gz=None,
                                         work=dptr(self.rnn_work), grads=None, N=self.n, T=self.T,
-                                        substeps=self.gen.adjoint_substeps, accumulate=0)
+                                        substeps=self.gen.adjoint_substeps, accumulate=0, zcols=Z_COLS)
             self.fwd_prog = L.Program([self.fwd_op])
         self.fwd_op.rtol, self.fwd_op.atol = self.gen.ode_rtol, self.gen.ode_atol
         self.bwd_op.substeps = self.gen.adjoint_substeps

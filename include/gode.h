@@ -133,7 +133,8 @@ int64_t gode_bn_bwd_work_size(int64_t M, int32_t C);
 /* ---- motion-latent ODE (models/mocogan_ode.py:6-17,123-148; torchdiffeq fixed-grid rk4 = Kutta 3/8) --------
  * forward: x[N][16] host-drawn noise -> pre-net Linear(16,64)/LReLU/Linear(64,16)/LReLU -> T-1 RK4(3/8) steps
  * of f(y)=W2 tanh(W1 y+b1)+b2 with step sizes dt[T-1] -> latent rows.  z is the generator's latent buffer
- * [rows][72] = [motion 16 | content 50 | zero pad 6]; row n*T+t (sel_t==NULL) or row n holding time sel_t[n]
+ * [rows][zcols] = [motion 16 | content 50 | zero pad] (zcols % 4 == 0, >= 68; the Python side uses 96 so that the
+ * first decoder GEMM has K % 32 == 0); row n*T+t (sel_t==NULL) or row n holding time sel_t[n]
  * (sample_images' row selection, models/mocogan.py:287-295).  content[N][50] is broadcast over the T rows.
  * traj[N][T][16] (nullable) keeps the whole trajectory for the adjoint pass. */
 typedef struct gode_ode_params {
@@ -144,17 +145,18 @@ typedef struct gode_ode_fwd_op {
   gode_ode_params p;
   const float* x; const float* content; const float* dt; const int32_t* sel_t;
   float* z; float* traj; int32_t N, T, substeps, prenet; /* prenet==0: linear=False (nn.Identity) */
+  int32_t zcols, pad_;
 } gode_ode_fwd_op;
 int gode_ode_fwd(const gode_ode_fwd_op* op, void* stream);
 /* adjoint backward (torchdiffeq odeint_adjoint semantics: per output interval ONE reverse-time RK4(3/8) step of
  * (y, a, g_theta), y reset to the stored trajectory, a += upstream grad) followed by the pre-net backward.
- * gz[rows][72]: gradient wrt the latent rows (only the 16 motion columns are read).  Parameter gradients are
+ * gz[rows][zcols]: gradient wrt the latent rows (only the 16 motion columns are read).  Parameter gradients are
  * reduced deterministically through work (>= gode_ode_bwd_work_size floats) and written (accumulate!=0: added) to
  * grads, laid out as the 8 tensors of gode_ode_params in order (2672 floats). */
 typedef struct gode_ode_bwd_op {
   gode_ode_params p;
   const float* x; const float* traj; const float* dt; const int32_t* sel_t; const float* gz;
-  float* work; float* grads; int32_t N, T, substeps, prenet, accumulate, pad_;
+  float* work; float* grads; int32_t N, T, substeps, prenet, accumulate, zcols;
 } gode_ode_bwd_op;
 int gode_ode_bwd(const gode_ode_bwd_op* op, void* stream);
 int64_t gode_ode_bwd_work_size(int32_t N);
@@ -173,7 +175,7 @@ typedef struct gode_odernn_fwd_op {
   gode_odernn_params p;
   const float* noise; const float* content; const int32_t* sel_t;
   float* z; float* hs; float* hp; int32_t* nsteps;
-  int32_t N, T; float rtol, atol;
+  int32_t N, T; float rtol, atol; int32_t zcols, pad_;
 } gode_odernn_fwd_op;
 int gode_odernn_fwd(const gode_odernn_fwd_op* op, void* stream);
 /* backward: GRU backward + continuous adjoint of every unit-interval solve, discretised with `substeps` fixed
@@ -182,7 +184,7 @@ int gode_odernn_fwd(const gode_odernn_fwd_op* op, void* stream);
 typedef struct gode_odernn_bwd_op {
   gode_odernn_params p;
   const float* noise; const float* hp; const int32_t* sel_t; const float* gz;
-  float* work; float* grads; int32_t N, T, substeps, accumulate;
+  float* work; float* grads; int32_t N, T, substeps, accumulate, zcols, pad_;
 } gode_odernn_bwd_op;
 int gode_odernn_bwd(const gode_odernn_bwd_op* op, void* stream);
 int64_t gode_odernn_bwd_work_size(int32_t N);

@@ -20,9 +20,9 @@ for N in (32, 1024, 1 << 16, 1 << 20):
     gz = torch.randn(N * T, 72, device="cuda")
     grads = torch.empty(L.ODE_NPARAM, device="cuda")
     work = torch.empty(L.lib().gode_ode_bwd_work_size(N), device="cuda")
-    f = L.OdeFwdOp(p=op, x=x.data_ptr(), content=None, dt=dt.data_ptr(), sel_t=None, z=z.data_ptr(), traj=None, N=N, T=T, substeps=1, prenet=1)
-    f2 = L.OdeFwdOp(p=op, x=x.data_ptr(), content=None, dt=dt.data_ptr(), sel_t=None, z=z.data_ptr(), traj=traj.data_ptr(), N=N, T=T, substeps=1, prenet=1)
-    b = L.OdeBwdOp(p=op, x=x.data_ptr(), traj=traj.data_ptr(), dt=dt.data_ptr(), sel_t=None, gz=gz.data_ptr(), work=work.data_ptr(), grads=grads.data_ptr(), N=N, T=T, substeps=1, prenet=1, accumulate=0)
+    f = L.OdeFwdOp(p=op, x=x.data_ptr(), content=None, dt=dt.data_ptr(), sel_t=None, z=z.data_ptr(), traj=None, N=N, T=T, substeps=1, prenet=1, zcols=72)
+    f2 = L.OdeFwdOp(p=op, x=x.data_ptr(), content=None, dt=dt.data_ptr(), sel_t=None, z=z.data_ptr(), traj=traj.data_ptr(), N=N, T=T, substeps=1, prenet=1, zcols=72)
+    b = L.OdeBwdOp(p=op, x=x.data_ptr(), traj=traj.data_ptr(), dt=dt.data_ptr(), sel_t=None, gz=gz.data_ptr(), work=work.data_ptr(), grads=grads.data_ptr(), N=N, T=T, substeps=1, prenet=1, accumulate=0, zcols=72)
     L.run_one(f2, st())
     for name, o, flop, byt in (("fwd", f, 61.4e3 + 4.1e3, 1088), ("bwd(adjoint)", b, 4 * 61.4e3, 2 * 1024 + 64)):
         reps = 20 if N < (1 << 18) else 5

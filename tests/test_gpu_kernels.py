@@ -250,7 +250,7 @@ def test_ode_forward_and_adjoint(N, T, sub):
     z = torch.full((N * T, 72), float("nan"), device="cuda")
     traj = torch.empty(N, T, 16, device="cuda")
     fop = L.OdeFwdOp(p=op, x=xd.data_ptr(), content=cd.data_ptr(), dt=dt.data_ptr(), sel_t=None, z=z.data_ptr(),
-                     traj=traj.data_ptr(), N=N, T=T, substeps=sub, prenet=1)
+                     traj=traj.data_ptr(), N=N, T=T, substeps=sub, prenet=1, zcols=72)
     L.run_one(fop, stream())
     zz = z.cpu().view(N, T, 72)
     tol = TOL if sub == 1 else 5e-4   # substeps divide dt in fp32 differently from the refined oracle grid
@@ -265,7 +265,7 @@ def test_ode_forward_and_adjoint(N, T, sub):
     grads = torch.full((L.ODE_NPARAM,), float("nan"), device="cuda")
     work = torch.empty(L.lib().gode_ode_bwd_work_size(N), device="cuda")
     bop = L.OdeBwdOp(p=op, x=xd.data_ptr(), traj=traj.data_ptr(), dt=dt.data_ptr(), sel_t=None, gz=gz.data_ptr(),
-                     work=work.data_ptr(), grads=grads.data_ptr(), N=N, T=T, substeps=1, prenet=1, accumulate=0)
+                     work=work.data_ptr(), grads=grads.data_ptr(), N=N, T=T, substeps=1, prenet=1, accumulate=0, zcols=72)
     L.run_one(bop, stream())
     g = grads.cpu()
     off = 0
@@ -289,7 +289,7 @@ def test_ode_golden_fixture_and_row_selection():
     z = torch.zeros(N * T, 72, device="cuda")
     traj = torch.empty(N, T, 16, device="cuda")
     fop = L.OdeFwdOp(p=op, x=x.data_ptr(), content=None, dt=dt.data_ptr(), sel_t=None, z=z.data_ptr(), traj=traj.data_ptr(),
-                     N=N, T=T, substeps=1, prenet=0)
+                     N=N, T=T, substeps=1, prenet=0, zcols=72)
     L.run_one(fop, stream())
     assert rel_err(traj.cpu().transpose(0, 1), g["sol"]) < TOL
     gz = torch.zeros(N * T, 72, device="cuda")
@@ -297,7 +297,7 @@ def test_ode_golden_fixture_and_row_selection():
     grads = torch.empty(L.ODE_NPARAM, device="cuda")
     work = torch.empty(L.lib().gode_ode_bwd_work_size(N), device="cuda")
     bop = L.OdeBwdOp(p=op, x=x.data_ptr(), traj=traj.data_ptr(), dt=dt.data_ptr(), sel_t=None, gz=gz.data_ptr(),
-                     work=work.data_ptr(), grads=grads.data_ptr(), N=N, T=T, substeps=1, prenet=0, accumulate=0)
+                     work=work.data_ptr(), grads=grads.data_ptr(), N=N, T=T, substeps=1, prenet=0, accumulate=0, zcols=72)
     L.run_one(bop, stream())
     gg = grads.cpu()
     for k, o, n in (("fn.0.weight", 2128, 256), ("fn.0.bias", 2384, 16), ("fn.2.weight", 2400, 256), ("fn.2.bias", 2656, 16)):
@@ -307,7 +307,7 @@ def test_ode_golden_fixture_and_row_selection():
     sel = torch.tensor([(3 * i) % T for i in range(N)], dtype=torch.int32).cuda()
     z2 = torch.zeros(N, 72, device="cuda")
     fop2 = L.OdeFwdOp(p=op, x=x.data_ptr(), content=None, dt=dt.data_ptr(), sel_t=sel.data_ptr(), z=z2.data_ptr(),
-                      traj=traj.data_ptr(), N=N, T=T, substeps=1, prenet=0)
+                      traj=traj.data_ptr(), N=N, T=T, substeps=1, prenet=0, zcols=72)
     L.run_one(fop2, stream())
     want = torch.stack([traj[i, int(sel[i])] for i in range(N)])
     assert torch.equal(z2[:, :16], want)

@@ -47,7 +47,7 @@ def test_odernn_kernels_against_oracle(N, T):
     hp_d = torch.empty(N, T, 16, device="cuda")
     nst = torch.zeros((N + 63) // 64 * T, dtype=torch.int32, device="cuda")
     fop = L.OdeRnnFwdOp(p=op, noise=nz.data_ptr(), content=content.data_ptr(), sel_t=None, z=z.data_ptr(), hs=None,
-                        hp=hp_d.data_ptr(), nsteps=nst.data_ptr(), N=N, T=T, rtol=1e-7, atol=1e-9)
+                        hp=hp_d.data_ptr(), nsteps=nst.data_ptr(), N=N, T=T, rtol=1e-7, atol=1e-9, zcols=72)
     L.run_one(fop, stream())
     zz = z.cpu().view(N, T, 72)
     assert rel_err(hp_d.cpu(), torch.stack(hps, dim=1).detach()) < 2e-5
@@ -60,7 +60,7 @@ def test_odernn_kernels_against_oracle(N, T):
     grads = torch.full((L.ODERNN_NPARAM,), float("nan"), device="cuda")
     work = torch.empty(L.lib().gode_odernn_bwd_work_size(N), device="cuda")
     bop = L.OdeRnnBwdOp(p=op, noise=nz.data_ptr(), hp=hp_d.data_ptr(), sel_t=None, gz=gz.data_ptr(), work=work.data_ptr(),
-                        grads=grads.data_ptr(), N=N, T=T, substeps=32, accumulate=0)
+                        grads=grads.data_ptr(), N=N, T=T, substeps=32, accumulate=0, zcols=72)
     L.run_one(bop, stream())
     g = grads.cpu()
     off = 0
