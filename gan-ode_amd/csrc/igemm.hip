@@ -600,14 +600,14 @@ __global__ void __launch_bounds__(256) conv_dot_kernel(const DotArgs d) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-enum { TILE_128x128 = 1, TILE_128x64 = 2, TILE_128x32 = 3, TILE_64x64 = 4 };
+enum { TILE_128x128 = 1, TILE_128x64 = 2, TILE_128x32 = 3, TILE_64x64 = 4, TILE_128x128_W8 = 5 };
 
 static int tile_bm(int tile) { return tile == TILE_64x64 ? 64 : 128; }
-static int tile_bn(int tile) { return tile == TILE_128x128 ? 128 : tile == TILE_128x32 ? 32 : 64; }
+static int tile_bn(int tile) { return (tile == TILE_128x128 || tile == TILE_128x128_W8) ? 128 : tile == TILE_128x32 ? 32 : 64; }
 
 static int pick_tile(const IgemmGeom& G, int requested) {
   requested %= 10;   // +10: double-LDS-buffer variant of the same tile (tuning knob; default is single-buffer)
-  if (requested >= TILE_128x128 && requested <= TILE_64x64) return requested;
+  if (requested >= TILE_128x128 && requested <= TILE_128x128_W8) return requested;
   if (G.Ncols <= 32) return TILE_128x32;
   if (G.Ncols <= 64) return TILE_128x64;
   int64_t blocks = 0;
@@ -635,7 +635,7 @@ static SplitPlan plan_split(const gode_igemm_op* op, const IgemmGeom& G, int til
   const gode_conv_geom& g = op->g;
   SplitPlan sp; sp.ksplit = 1; sp.slabs_per_split = 0; sp.positions = g.N * G.Xd * G.Xh * G.Xw;
   if (!fast_geometry(G) || G.Ncols <= 4 || !strides_allow_vec(op, G) || op->tile >= 10) return sp;
-  const int bm = tile == 4 ? 64 : 128, bn = tile == 1 ? 128 : (tile == 3 ? 32 : 64);
+  const int bm = tile == 4 ? 64 : 128, bn = (tile == 1 || tile == 5) ? 128 : (tile == 3 ? 32 : 64);
   int64_t blocks = 0; int max_slabs = 0, min_slabs = 1 << 30;
   for (int i = 0; i < G.nphase; ++i) {
     blocks += (int64_t)gode_ceil_div(G.ph[i].M, bm) * gode_ceil_div(G.Ncols, bn);
@@ -792,6 +792,7 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
     case TILE_128x64: return launch<2, 2, 2, 1>(A, vec, max_mblk, sb, sp, st);
     case TILE_128x32: return launch<4, 1, 1, 1>(A, vec, max_mblk, sb, sp, st);
     case TILE_64x64: return launch<2, 2, 1, 1>(A, vec, max_mblk, sb, sp, st);
+    case TILE_128x128_W8: return launch<4, 2, 1, 2>(A, vec, max_mblk, sb, sp, st);
   }
   return GODE_E_ARG;
 }

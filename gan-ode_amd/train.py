@@ -82,7 +82,11 @@ class FusedAdam(torch.optim.Optimizer):
     uses torch.optim.Adam's keys (step / exp_avg / exp_avg_sq) so checkpoints interchange."""
 
     def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8, weight_decay=1e-5):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # the extra keys are torch.optim.Adam's remaining hyper-parameters at their defaults, carried so that a
+        # state_dict saved here loads into torch.optim.Adam and vice versa (mnist_moco_ode.py:92-103,175-190)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False,
+                                      maximize=False, foreach=None, capturable=False, differentiable=False,
+                                      fused=None, decoupled_weight_decay=False))
 
     @torch.no_grad()
     def step(self, closure=None, grads: Optional[dict] = None, gscale: float = 1.0):

@@ -389,3 +389,44 @@ def test_full_width_train_iterations_batch8_against_oracle():
         rev, _ = ogen.sample_videos(4)
     # two Adam steps in, a handful of +-lr weight flips (see above) are visible at the 1e-2 level in eval-mode frames
     assert rel_err(ev.cpu(), rev) < 3e-2
+
+
+def test_checkpoint_interchange_with_stock_torch(tmp_path):
+    """the checkpoint format of mnist_moco_ode.py:175-190 ({'epoch', 'model_state_dict': [...],
+    'optimizer_state_dict': [...]}, torch.save) written from the HIP path loads into stock torch modules + torch.optim.Adam
+    (and back), and training continues identically from it."""
+    g = golden("train_mnist_tiny.npz")
+    s = int(g["seed"])
+    gen, dv, di = G.build_mnist(ngf=8, ndf=8)
+    for m, p in ((gen, "gen"), (dv, "vid"), (di, "img")):
+        load_sd(m, g, f"w0/{p}")
+        m.cuda()
+    tr = G.GanTrainer(gen, dv, di)
+    imgs = [_f32(g[f"real_img/0/{i}"]) for i in range(2)]
+    vids = [_f32(g[f"real_vid/0/{i}"]) for i in range(2)]
+    seed_all(s + 1)
+    G.train_step(tr, [t.cuda() for t in imgs], [t.cuda() for t in vids])
+    path = tmp_path / "state_normal0.ckpt"
+    torch.save({"epoch": 0,
+                "model_state_dict": [gen.state_dict(), dv.state_dict(), di.state_dict()],
+                "optimizer_state_dict": [tr.gen_opt.state_dict(), tr.vid_opt.state_dict(), tr.img_opt.state_dict()]}, path)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    ogen, odv, odi = M.build_mnist(ngf=8, ndf=8)
+    opts = M.make_optimizers(ogen, odv, odi)
+    for m, sd in zip((ogen, odv, odi), ck["model_state_dict"]):
+        m.load_state_dict(sd)                                   # strict: identical keys
+    for o, sd in zip(opts, ck["optimizer_state_dict"]):
+        o.load_state_dict(sd)
+    assert int(opts[0].state[ogen.main[0].weight]["step"]) == 1 and ogen.recurrent.weight_ih not in opts[0].state
+    # continue one iteration on both sides from the checkpoint
+    imgs1 = [_f32(g[f"real_img/1/{i}"]) for i in range(2)]
+    vids1 = [_f32(g[f"real_vid/1/{i}"]) for i in range(2)]
+    seed_all(s + 2)
+    got = [float(v) for v in G.train_step(tr, [t.cuda() for t in imgs1], [t.cuda() for t in vids1])]
+    seed_all(s + 2)
+    want = [float(v) for v in M.train_step(ogen, odv, odi, opts, imgs1, vids1)]
+    assert np.allclose(got, want, rtol=2e-4, atol=0), (got, want)
+    assert np.allclose(got, g["losses"][1], rtol=2e-4, atol=0)
+    # and the other direction: a stock-torch optimiser state loads into FusedAdam
+    tr.gen_opt.load_state_dict(opts[0].state_dict())
+    assert int(tr.gen_opt.state[gen.main[0].weight]["step"]) == 2
