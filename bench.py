@@ -125,6 +125,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--train-steps", type=int, default=10, help="iterations for the G/D step timings")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="only build the plan and run the per-layer roofline launches (for `rocprofv3 --kernel-trace "
+                         "--stats -- python bench.py --roofline-only`, whose per-kernel averages must agree with the "
+                         "HIP-event timings printed here)")
     ap.add_argument("--config", default="mnist", choices=["mnist", "ucf", "odernn"],
                     help="mnist = BASELINE configs[1] (default, the headline); ucf = configs[3] shapes (batch 16, "
                          "3x64x64, rk4 as the code does); odernn = configs[4] (ODE-RNN latent, batch 32)")
@@ -160,6 +164,10 @@ def main():
         for m in (gen, dv, di):
             for t in list(m.parameters()) + list(m.buffers()):
                 dist.broadcast(t.data, src=0)
+
+    if a.roofline_only:
+        print(json.dumps({"roofline": _kernel_roofline(gen)}))
+        return
 
     def sample():
         with torch.no_grad():
