@@ -337,3 +337,42 @@ def test_bce_and_adam():
         L.run_one(L.AdamOp(p=pd.data_ptr(), g=gd.data_ptr(), m=m.data_ptr(), v=v.data_ptr(), n=1000, lr=2e-4, beta1=0.5,
                            beta2=0.999, eps=1e-8, weight_decay=1e-5, gscale=1.0, step=step), stream())
     assert float((pd.cpu() - pr.detach()).abs().max()) < 1e-6
+
+
+FULL_SIZE = [
+    # BASELINE configs[1] layer shapes at full size (R = 512 latent rows / batch 32 clips): (Ci, Co, xi, k, s, p, N)
+    (256, 512, (1, 8, 8), (1, 4, 4), (1, 2, 2), (0, 1, 1), 512),      # decoder ConvT 512->256
+    (128, 256, (1, 16, 16), (1, 4, 4), (1, 2, 2), (0, 1, 1), 512),    # decoder ConvT 256->128
+    (64, 128, (1, 32, 32), (1, 4, 4), (1, 2, 2), (0, 1, 1), 512),     # decoder ConvT 128->64
+    (64, 128, (15, 15, 15), (2, 2, 2), (1, 2, 2), (0, 1, 1), 32),     # video-D Conv3d 64->128
+    (128, 256, (14, 8, 8), (2, 2, 2), (1, 2, 2), (0, 1, 1), 32),      # video-D Conv3d 128->256
+    (256, 512, (13, 5, 5), (2, 2, 2), (1, 2, 2), (0, 1, 1), 32),      # video-D Conv3d 256->512
+]
+
+
+@pytest.mark.parametrize("case", FULL_SIZE)
+def test_full_size_adjoint_identities(case):
+    """Size-independent property at BASELINE's full sizes (too large for the CPU oracle to redo in seconds): the three
+    kernels of one layer are mutually adjoint,  <conv(x; W), y> = <x, conv^T(y; W)> = <W, wgrad(x, y)>,  which ties
+    FPROP, DGRAD (all stride phases, XCD-remapped grids, split-K where planned) and WGRAD together at full size."""
+    Ci, Co, xi, k, s, p, N = case
+    yo = tuple(conv_out(xi[a], k[a], s[a], p[a]) for a in range(3))
+    g = make_geom(N, Ci, Co, xi, yo, k, s, p)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(N, *xi, Ci, device="cuda", generator=gen)            # channels-last
+    y = torch.randn(N, *yo, Co, device="cuda", generator=gen)
+    w = torch.randn(Co, Ci, *k, device="cuda", generator=gen) * 0.05
+    fx, _ = igemm(g, L.FPROP, x, w, (N, *yo, Co))
+    dy, _ = igemm(g, L.DGRAD, y, w, (N, *xi, Ci))
+    lib = L.lib()
+    dw = torch.empty_like(w)
+    op = L.WgradOp(g=g, act=L.ACT_NONE, xform_on_y=0, splits=0, accumulate=0, x=x.data_ptr(), y=y.data_ptr(), dw=dw.data_ptr())
+    work = torch.empty(lib.gode_wgrad_work_size(C.byref(op)), device="cuda")
+    op.work = work.data_ptr()
+    L.run_one(op, stream())
+    a = float((fx.double() * y.double()).sum())
+    b = float((x.double() * dy.double()).sum())
+    c = float((w.double() * dw.double()).sum())
+    scale = float((fx.double().norm() * y.double().norm()))
+    assert abs(a - b) / scale < 1e-6 and abs(a - c) / scale < 1e-6, (a, b, c, scale)
+    assert torch.isfinite(fx).all() and torch.isfinite(dy).all() and torch.isfinite(dw).all()

@@ -430,3 +430,49 @@ def test_checkpoint_interchange_with_stock_torch(tmp_path):
     # and the other direction: a stock-torch optimiser state loads into FusedAdam
     tr.gen_opt.load_state_dict(opts[0].state_dict())
     assert int(tr.gen_opt.state[gen.main[0].weight]["step"]) == 2
+
+
+def test_data_parallel_step_path_on_one_rank_nccl():
+    """The multi-GPU optimiser path (flat bucket -> RCCL all-reduce -> Adam reading the reduced bucket with 1/world
+    folded in) exercised on a single-rank NCCL group with the world size forced to 2: with one rank the all-reduce is
+    the identity, so every gradient is halved -- compared against a plain step fed the same halved gradients."""
+    import os
+    import torch.distributed as dist
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        g = golden("train_mnist_tiny.npz")
+        s = int(g["seed"])
+        nets = []
+        for _ in range(2):
+            gen, dv, di = G.build_mnist(ngf=8, ndf=8)
+            for m, p in ((gen, "gen"), (dv, "vid"), (di, "img")):
+                load_sd(m, g, f"w0/{p}")
+                m.cuda()
+            nets.append((gen, dv, di))
+        tr_dp = G.GanTrainer(*nets[0])
+        tr_dp.world = 2                                   # pretend there is a second rank
+        tr_ref = G.GanTrainer(*nets[1])
+        real_img = _f32(g["real_img/0/0"]).cuda()
+        seed_all(s + 1)
+        l_dp = tr_dp.d_image_step(real_img)
+        # reference: same forward/backward, then Adam on gradients scaled by 1/2
+        seed_all(s + 1)
+        tr_ref.img_opt.zero_grad()
+        pr, _ = tr_ref.dis_img(real_img)
+        with torch.no_grad():
+            fake, _ = tr_ref.gen.sample_images(real_img.shape[0])
+        pf, _ = tr_ref.dis_img(fake)
+        loss = G.bce_with_logits_const(pr, 1.0) + G.bce_with_logits_const(pf, 0.0)
+        loss.backward()
+        tr_ref.img_opt.step(gscale=0.5)
+        assert abs(float(l_dp) - float(loss.detach())) < 1e-6
+        for (k, a), (_, b) in zip(nets[0][2].state_dict().items(), nets[1][2].state_dict().items()):
+            assert torch.equal(a, b), k
+    finally:
+        if created:
+            dist.destroy_process_group()
