@@ -259,6 +259,8 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const IgemmArgs a) {
   }
 }
 
+__device__ __attribute__((aligned(16))) const float gode_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
 // ---------------------------------------------------------------------------------------------------------------
 // FAST variant for the layers that carry the FLOPs: vector gather, Cg % 32 == 0 (so a 32-wide K slab never straddles
 // a tap and the tap decode is wave-uniform scalar work), K % 32 == 0.  The loop body is one basic block: loads are
@@ -267,14 +269,20 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const IgemmArgs a) {
 // DB=true : two LDS buffers, one barrier per slab, staging interleaved with this wave's own MFMAs.
 // DB=false: one LDS buffer (half the LDS => twice the resident workgroups, 4 waves per SIMD), two barriers per slab;
 //           the staging of one workgroup is covered by the MFMAs of the three others on the SIMD.
-template <int WM, int WN, int TM, int TN, bool DB, bool XF>
+// MODE 2 (LDS-DMA): the slab is written to LDS by `global_load_lds_dwordx4` (no VGPR round trip, no ds_write pass);
+//           two unpadded LDS buffers whose 16-byte chunks are XOR-swizzled through the SOURCE address (the DMA
+//           destination is lane-linear), one barrier per slab.  Transform-free instantiation only.
+template <int WM, int WN, int TM, int TN, int MODE, bool XF>
 __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs a) {
-  constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32, LDK = 36;
+  constexpr bool DB = MODE == 1, GL = MODE == 2;
+  static_assert(!(GL && XF), "the LDS-DMA path cannot transform on load");
+  constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32, LDK = GL ? 32 : 36;
   constexpr int RPP = NT / 8;
   constexpr int AP = BM / RPP, BP = BN / RPP;
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/loader mismatch");
+  static_assert(!GL || RPP % 16 == 0, "swizzle key must not depend on the loader pass");
   constexpr int BUF = (BM + BN) * LDK;
-  constexpr int NBUF = DB ? 2 : 1;
+  constexpr int NBUF = (DB || GL) ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float smem[NBUF * BUF + BM * 5];
   int* rowinfo = reinterpret_cast<int*>(smem + NBUF * BUF);
   int* outoff = rowinfo + BM * 4;
@@ -314,7 +322,9 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
     const int r = (tid >> 3) + RPP * i;
     rbase[i] = rowinfo[r * 4 + 0]; rbd[i] = rowinfo[r * 4 + 1]; rbh[i] = rowinfo[r * 4 + 2]; rbw[i] = rowinfo[r * 4 + 3];
   }
-  const int kchunk = (tid & 7) * 4;
+  // GL: LDS position (tid&7) of row r holds K chunk (tid&7) ^ key(r), key(r) = (r>>1)&7 -- two 128-byte rows share
+  // one 256-byte bank row, so a 16-lane ds_read_b128 group (rows r..r+15, same chunk) touches 16 distinct slots
+  const int kchunk = GL ? (((tid & 7) ^ ((tid >> 4) & 7)) * 4) : (tid & 7) * 4;
   const int J = a.G.J, Gd = a.G.Gd, Gh = a.G.Gh, Gw = a.G.Gw;
   const int nslab_all = P.K >> 5;
   const int s_begin = split * a.slabs_per_split;
@@ -344,9 +354,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
   int roff[AP];          // element offset of (row, current tap, channel 0); refreshed only when the tap changes
   bool tap_dirty = true;
 
-  auto fetch = [&](int slab) {
-    const int c = c0 + kchunk;
-    if (XF && xf) { sc4 = *reinterpret_cast<const f32x4*>(a.scale + c); sh4 = *reinterpret_cast<const f32x4*>(a.shift + c); }
+  auto tap_refresh = [&]() {
     if (tap_dirty) {     // wave-uniform: once per tap (every Cg/32 slabs), not per slab
       amask = 0;
 #pragma unroll
@@ -358,17 +366,41 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
       }
       tap_dirty = false;
     }
-#pragma unroll
-    for (int i = 0; i < AP; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a.src + roff[i] + (((amask >> i) & 1u) ? c0 : 0));
-#pragma unroll
-    for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + slab * 32);
-    // advance the odometer (uniform)
+  };
+  auto advance = [&]() {   // the tap odometer (uniform)
     c0 += 32;
     if (c0 >= Cg) {
       c0 = 0;
       tap_dirty = true;
       if (++jw == P.Tw) { jw = 0; if (++jh == P.Th) { jh = 0; ++jd; } }
     }
+  };
+  auto fetch = [&](int slab) {
+    const int c = c0 + kchunk;
+    if (XF && xf) { sc4 = *reinterpret_cast<const f32x4*>(a.scale + c); sh4 = *reinterpret_cast<const f32x4*>(a.shift + c); }
+    tap_refresh();
+#pragma unroll
+    for (int i = 0; i < AP; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a.src + roff[i] + (((amask >> i) & 1u) ? c0 : 0));
+#pragma unroll
+    for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + slab * 32);
+    advance();
+  };
+  // LDS-DMA issue of one slab into buffer `buf`: wave w fills rows 8w..8w+7 (+RPP per pass), 1 KiB per instruction
+  auto dma = [&](int slab, int buf) {
+    tap_refresh();
+    float* dstA = smem + buf * BUF + wave * 8 * LDK;
+    float* dstB = dstA + BM * LDK;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const float* g = ((amask >> i) & 1u) ? a.src + roff[i] + c0 : gode_zero16;   // padding taps read a zero page
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(dstA + RPP * i * LDK), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + slab * 32),
+                                       (__attribute__((address_space(3))) void*)(dstB + RPP * i * LDK), 16, 0, 0);
+    advance();
   };
   auto stageA = [&](int buf) {
     float* As = smem + buf * BUF;
@@ -403,15 +435,17 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
+  const int frag_row = lane & 31, frag_k = GL ? 0 : (lane >> 5) * 4;
+  const int fkey = (frag_row >> 1) & 7, fhalf = lane >> 5;
   const float* Abase = smem + (wm * TM * 32 + frag_row) * LDK + frag_k;
   const float* Bbase = smem + BM * LDK + (wn * TN * 32 + frag_row) * LDK + frag_k;
   auto mma_group = [&](int buf, int kg) {
     f32x4 af[TM], bf[TN];
+    const int koff = GL ? (((2 * kg + fhalf) ^ fkey) * 4) : kg * 8;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Abase + buf * BUF + i * 32 * LDK + kg * 8);
+    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Abase + buf * BUF + i * 32 * LDK + koff);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bbase + buf * BUF + j * 32 * LDK + kg * 8);
+    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bbase + buf * BUF + j * 32 * LDK + koff);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -421,7 +455,18 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
   };
 
-  if (nslab > 0) {
+  if (GL) {
+    if (nslab > 0) {
+      dma(0, 0);
+      for (int s = 0; s < nslab; ++s) {
+        __syncthreads();                      // waits vmcnt(0): slab s has landed; every wave is done with slab s-1
+        if (s + 1 < nslab) dma(s + 1, (s + 1) & 1);
+        const int buf = s & 1;
+        mma_group(buf, 0); mma_group(buf, 1); mma_group(buf, 2); mma_group(buf, 3);
+      }
+      __syncthreads();
+    }
+  } else if (nslab > 0) {
   fetch(0);
   if (DB) {
     stageA(0);
@@ -721,12 +766,16 @@ static int launch(IgemmArgs& A, bool vec, int max_mblk, bool double_buf, const S
     A.xcd_mode = mode;
     dim3 g1(MB * NC * sp.ksplit);
     const bool has_xf = A.scale != nullptr || A.act != GODE_ACT_NONE;
-    if (double_buf) {
-      if (has_xf) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, true, true>), g1, block, 0, st, A);
-      else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, true, false>), g1, block, 0, st, A);
+    static const char* genv = getenv("GODE_IGEMM_GLDS");
+    const bool glds = genv ? atoi(genv) != 0 : true;   // default; GODE_IGEMM_GLDS=0 selects register staging
+    if (!has_xf && glds && !double_buf) {
+      hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 2, false>), g1, block, 0, st, A);
+    } else if (double_buf) {
+      if (has_xf) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 1, true>), g1, block, 0, st, A);
+      else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 1, false>), g1, block, 0, st, A);
     } else {
-      if (has_xf) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false, true>), g1, block, 0, st, A);
-      else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false, false>), g1, block, 0, st, A);
+      if (has_xf) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 0, true>), g1, block, 0, st, A);
+      else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 0, false>), g1, block, 0, st, A);
     }
     if (sp.ksplit > 1) {
       GODE_LAUNCH_CHECK();

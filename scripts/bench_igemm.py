@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", default="")
 ap.add_argument("--tiles", default="0")
+ap.add_argument("--noxf", action="store_true", help="forward GEMMs on materialised (already activated) inputs")
 a = ap.parse_args()
 lib = L.lib()
 R = int(os.environ.get("GODE_BENCH_ROWS", "512"))
@@ -45,7 +46,7 @@ def run_igemm(name, g, direction, flop, xform=True, tiles=(0,)):
     Cg = src_dims[-1]
     sc, sh = torch.rand(Cg, device="cuda") + 0.5, torch.randn(Cg, device="cuda")
     for tile in tiles:
-        op = L.IgemmOp(g=g, dir=direction, act=L.ACT_RELU, epilogue=L.EPI_RAW, tile=tile, src=src.data_ptr(),
+        op = L.IgemmOp(g=g, dir=direction, act=L.ACT_RELU if xform else L.ACT_NONE, epilogue=L.EPI_RAW, tile=tile, src=src.data_ptr(),
                        wpack=wp.data_ptr(), out=out.data_ptr(), scale=sc.data_ptr() if xform else None,
                        shift=sh.data_ptr() if xform else None)
         work = torch.empty(max(lib.gode_igemm_work_size(C.byref(op)), 1), device="cuda")
@@ -78,7 +79,7 @@ dec = [("dec L1 convT 512->256 4->8", make_geom(R, 256, 512, (1, 8, 8), (1, 4, 4
 flop_dec = 2.0 * 33554432 * R
 if a.only in ("", "dec"):
     for n, g in dec:
-        run_igemm(n + " fwd(DGRAD)", g, L.DGRAD, flop_dec, tiles=tiles)
+        run_igemm(n + " fwd(DGRAD)", g, L.DGRAD, flop_dec, xform=not a.noxf, tiles=tiles)
     for n, g in dec:
         run_igemm(n + " bwd-data(FPROP)", g, L.FPROP, flop_dec, xform=False, tiles=tiles)
 if a.only in ("", "wgrad"):
