@@ -173,12 +173,18 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgradArgs a) {
 
 // FAST path (vector loads on both operands): branch-free loop body (clamped loads + masks, magic-number position
 // decode), ONE LDS buffer (32 KB at 128x128 => four workgroups per CU cover each other's staging).
-template <int WM, int WN, int TM, int TN>
+__device__ __attribute__((aligned(16))) const float gode_wg_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// GL: transform-free operands go global -> LDS by `global_load_lds_dwordx4` (the [position][channel] image is already
+// lane-linear: thread t of a loader pass owns 16-byte chunk t), two LDS buffers, one barrier per 32-position slab.
+template <int WM, int WN, int TM, int TN, bool GL>
 __global__ void __launch_bounds__(256) wgrad_fast_kernel(const WgradArgs a) {
   constexpr int NT = 256, BI = WM * TM * 32, BJ = WN * TN * 32;
   constexpr int YC = BI / 4, XC = BJ / 4, YR = NT / YC, XR = NT / XC, YP = 32 / YR, XP = 32 / XR;
   static_assert(YP >= 1 && XP >= 1, "tile too narrow for the loader");
-  __shared__ __attribute__((aligned(16))) float smem[32 * (BI + BJ)];
+  static_assert(!GL || (YC % 64 == 0 || 64 % YC == 0), "loader pass must be lane-linear");
+  constexpr int BUF = 32 * (BI + BJ);
+  __shared__ __attribute__((aligned(16))) float smem[(GL ? 2 : 1) * BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int jblk = blockIdx.x, iblk = blockIdx.y, z = blockIdx.z;
@@ -229,6 +235,34 @@ __global__ void __launch_bounds__(256) wgrad_fast_kernel(const WgradArgs a) {
       xmask |= (ok ? 1u : 0u) << p;
     }
   };
+  // LDS-DMA issue of one slab: the loader's (row, chunk) of a pass is tid-linear, so wave w writes 1 KiB at
+  // pass base + 256*w floats; masked rows (tail, padding taps) read a zero page
+  auto dma = [&](int slab, int buf) {
+    const int mb = m_begin + slab * 32;
+    float* Ys = smem + buf * BUF + wave * 256;
+    float* Xs = smem + buf * BUF + 32 * BI + wave * 256;
+#pragma unroll
+    for (int p = 0; p < YP; ++p) {
+      const int m = mb + yr0 + p * YR;
+      const bool ok = m < m_end && yok;
+      const float* gp = ok ? yptr + (int64_t)m * g.Co : gode_wg_zero16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                       (__attribute__((address_space(3))) void*)(Ys + p * YR * BI), 16, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const uint32_t m = mb + xr0 + p * XR;
+      const uint32_t t1 = fdiv(m, a.dWo), qw = m - t1 * g.Wo;
+      const uint32_t t2 = fdiv(t1, a.dHo), qh = t1 - t2 * g.Ho;
+      const uint32_t img = fdiv(t2, a.dDo), qd = t2 - img * g.Do;
+      const int id = (int)qd * g.sd - g.pd + xkd, ih = (int)qh * g.sh - g.ph + xkh, iw = (int)qw * g.sw - g.pw + xkw;
+      const bool ok = (int)m < m_end && xok && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi &&
+                      (unsigned)iw < (unsigned)g.Wi;
+      const float* gp = ok ? xptr + ((int)img * a.xsN + id * a.xsD + ih * a.xsH + iw * a.xsW) : gode_wg_zero16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                       (__attribute__((address_space(3))) void*)(Xs + p * XR * BJ), 16, 0, 0);
+    }
+  };
   auto stage = [&]() {
     float* Ys = smem;
     float* Xs = smem + 32 * BI;
@@ -258,47 +292,59 @@ __global__ void __launch_bounds__(256) wgrad_fast_kernel(const WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // MFMA row r of sub-tile i is output channel TM*r + i (and column c of sub-tile j is weight column TN*c + j): a
+  // lane then reads its TM (TN) operands of one k as ONE ds_read_b32/b64 instead of TM (TN) separate reads
+  typedef float __attribute__((ext_vector_type(TM))) av_t;
+  typedef float __attribute__((ext_vector_type(TN))) bv_t;
   const int fr = lane & 31, fh = lane >> 5;
-  const float* Yr = smem + fh * BI + wm * TM * 32 + fr;
-  const float* Xr = smem + 32 * BI + fh * BJ + wn * TN * 32 + fr;
-  auto mma_slab = [&]() {
+  const float* Yr = smem + fh * BI + wm * TM * 32 + fr * TM;
+  const float* Xr = smem + 32 * BI + fh * BJ + wn * TN * 32 + fr * TN;
+  auto mma_slab = [&](int buf) {
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      float af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = Yr[ks * 2 * BI + i * 32];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = Xr[ks * 2 * BJ + j * 32];
+      const av_t af = *reinterpret_cast<const av_t*>(Yr + buf * BUF + ks * 2 * BI);
+      const bv_t bf = *reinterpret_cast<const bv_t*>(Xr + buf * BUF + ks * 2 * BJ);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
   };
-  if (nslab > 0) {
+  if (GL) {
+    if (nslab > 0) {
+      dma(0, 0);
+      for (int s = 0; s < nslab; ++s) {
+        __syncthreads();                 // waits vmcnt(0): slab s has landed; every wave is done with slab s-1
+        if (s + 1 < nslab) dma(s + 1, (s + 1) & 1);
+        mma_slab(s & 1);
+      }
+    }
+  } else if (nslab > 0) {
     fetch(0);
     for (int s = 0; s + 1 < nslab; ++s) {
       stage();
       __syncthreads();
       fetch(s + 1);
-      mma_slab();
+      mma_slab(0);
       __syncthreads();
     }
     stage();
     __syncthreads();
-    mma_slab();
+    mma_slab(0);
   }
 
   float* dst = a.work + (int64_t)z * g.Co * a.Kt;
+  const int col0 = jblk * BJ + wn * TN * 32 + (lane & 31) * TN;      // Kt % 4 == 0 here, so col0 < Kt covers the pair
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = jblk * BJ + (wn * TN + j) * 32 + (lane & 31);
+    for (int r = 0; r < 16; ++r) {
+      const int row = iblk * BI + wm * TM * 32 + TM * ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) + i;
+      if (row < g.Co && col0 < a.Kt) {
+        bv_t v;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = iblk * BI + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < g.Co && col < a.Kt) dst[(int64_t)row * a.Kt + col] = acc[i][j][r];
+        for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
+        *reinterpret_cast<bv_t*>(dst + (int64_t)row * a.Kt + col0) = v;
       }
     }
 }
@@ -442,16 +488,27 @@ __global__ void __launch_bounds__(256) wgrad_reduce_small_kernel(const float* wo
 static int wg_tile(const gode_conv_geom& g) { return g.Co <= 32 ? 0 : (g.Co <= 64 ? 1 : 2); }
 static int wg_bi(int t) { return t == 0 ? 32 : (t == 1 ? 64 : 128); }
 
+// Position splits of the weight-gradient GEMM.  All workgroups carry equal work, so the launch time is the busiest
+// CU's share: the grid (tiles x splits) should be a multiple of the 256 CUs and give each CU >= 2 resident workgroups
+// (measured on the decoder layers: 512 workgroups 96-105 TFLOP/s, 640 workgroups 84-88, 256 workgroups 90-99).  More
+// splits also cost one more [Co][Kt] slab to write and reduce, ~114 positions' worth of GEMM time each.
 extern "C" int gode_wgrad_auto_splits(const gode_conv_geom* g) {
   const int taps = g->kd * g->kh * g->kw, Kt = taps * g->Ci;
   const int64_t M = (int64_t)g->N * g->Do * g->Ho * g->Wo;
   const int64_t tiles = (int64_t)gode_ceil_div(g->Co, wg_bi(wg_tile(*g))) * gode_ceil_div(Kt, 128);
-  int64_t s = (640 + tiles - 1) / tiles;
-  const int64_t cap = (M + 63) / 64;
-  if (s > cap) s = cap;
-  if (s > 256) s = 256;
-  if (s < 1) s = 1;
-  return (int)s;
+  int64_t cap = (M + 63) / 64;
+  if (cap > 256) cap = 256;
+  if (cap < 1) cap = 1;
+  int best = 1; double best_cost = 1e300;
+  for (int64_t s = 1; s <= cap; ++s) {
+    const double blocks = (double)(tiles * s);
+    const double rounds = (double)((tiles * s + 255) / 256);
+    const double balance = blocks / (rounds * 256.0);                 // busiest CU's share vs the mean
+    const double overlap = blocks >= 512.0 ? 1.0 : 0.92;              // a lone workgroup per CU cannot hide its barriers
+    const double cost = (1.0 + 114.0 * (double)s / (double)M) / (balance * overlap);
+    if (cost < best_cost - 1e-12) { best_cost = cost; best = (int)s; }
+  }
+  return best;
 }
 
 static bool wg_thin(const gode_conv_geom& g) {
@@ -477,7 +534,12 @@ template <int WM, int WN, int TM, int TN>
 static int wg_launch(const WgradArgs& A, bool vx, bool vy, int splits, hipStream_t st) {
   constexpr int BI = WM * TM * 32, BJ = WN * TN * 32;
   dim3 grid(gode_ceil_div(A.Kt, BJ), gode_ceil_div(A.g.Co, BI), splits), block(256);
-  if (vx && vy && getenv("GODE_WGRAD_GENERIC") == nullptr) hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN>), grid, block, 0, st, A);
+  static const char* genv = getenv("GODE_WGRAD_GLDS");
+  const bool glds = (genv ? atoi(genv) != 0 : true) && A.scale == nullptr && A.act == GODE_ACT_NONE;
+  if (vx && vy && getenv("GODE_WGRAD_GENERIC") == nullptr) {
+    if (glds) hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, true>), grid, block, 0, st, A);
+    else hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, false>), grid, block, 0, st, A);
+  }
   else if (vx && vy) hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, true, true>), grid, block, 0, st, A);
   else if (vx) hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, true, false>), grid, block, 0, st, A);
   else if (vy) hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, false, true>), grid, block, 0, st, A);

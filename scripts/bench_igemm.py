@@ -64,8 +64,9 @@ def run_wgrad(name, g, flop, on_y):
     dw = torch.empty(g.Co, g.Ci, g.kd, g.kh, g.kw, device="cuda")
     Cx = g.Co if on_y else g.Ci
     sc, sh = torch.rand(Cx, device="cuda") + 0.5, torch.randn(Cx, device="cuda")
-    op = L.WgradOp(g=g, act=L.ACT_RELU, xform_on_y=on_y, splits=0, accumulate=0, x=x.data_ptr(), y=y.data_ptr(),
-                   scale=sc.data_ptr(), shift=sh.data_ptr(), dw=dw.data_ptr())
+    op = L.WgradOp(g=g, act=L.ACT_NONE if a.noxf else L.ACT_RELU, xform_on_y=on_y, splits=0, accumulate=0,
+                   x=x.data_ptr(), y=y.data_ptr(), scale=None if a.noxf else sc.data_ptr(),
+                   shift=None if a.noxf else sh.data_ptr(), dw=dw.data_ptr())
     work = torch.empty(lib.gode_wgrad_work_size(C.byref(op)), device="cuda")
     op.work = work.data_ptr()
     ms = timeit(op)
