@@ -185,7 +185,7 @@ def main():
     wtr = max(1, min(3, k))
     d_ms = _timed(lambda: (tr.d_image_step(imgs[0]), tr.d_video_step(vids[0])), k, wtr, distributed) / k * 1e3
     g_ms = _timed(lambda: tr.g_step(B), k, wtr, distributed) / k * 1e3
-    it_ms = _timed(lambda: tr.step(imgs, vids), k, 1, distributed) / k * 1e3
+    it_ms = _timed(lambda: tr.step(imgs, vids), k, wtr, distributed) / k * 1e3
 
     if rank == 0:
         roof = _kernel_roofline(gen) if a.config == "mnist" else None

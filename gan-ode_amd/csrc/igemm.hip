@@ -595,6 +595,41 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce_kernel(const float* w
   }
 }
 
+// Vector form (Ncols % 4 == 0): a workgroup owns 16 positions x 64 columns, one float4 per thread, so even a
+// 512-position x 512-column output spreads over 256 workgroups with ksplit independent 16-byte loads per thread (the
+// column-loop form above ran 32 workgroups and took 84 us for 34 MB of partials).  Same summation orders as above.
+__global__ void __launch_bounds__(256) igemm_splitk_reduce_vec_kernel(const float* work, float* out, float* stats, int positions,
+                                                                      int Ncols, int ksplit, int epilogue) {
+  __shared__ float red[2][SPLITK_ROWS][64];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int row = blockIdx.x * SPLITK_ROWS + ty, col = blockIdx.y * 64 + tx * 4;
+  const int64_t numel = (int64_t)positions * Ncols;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (row < positions && col < Ncols) {
+    const float* p = work + (int64_t)row * Ncols + col;
+#pragma unroll 8
+    for (int sp = 0; sp < ksplit; ++sp) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(p + sp * numel);
+      v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    }
+    f32x4 o = v;
+    if (epilogue == GODE_EPI_TANH) { o[0] = tanhf(v[0]); o[1] = tanhf(v[1]); o[2] = tanhf(v[2]); o[3] = tanhf(v[3]); }
+    *reinterpret_cast<f32x4*>(out + (int64_t)row * Ncols + col) = o;
+  }
+  if (stats) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][ty][tx * 4 + e] = v[e]; red[1][ty][tx * 4 + e] = v[e] * v[e]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < SPLITK_ROWS; ++r) acc += red[which][r][c];
+      if (blockIdx.y * 64 + c < Ncols) stats[((int64_t)blockIdx.x * 2 + which) * Ncols + blockIdx.y * 64 + c] = acc;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Thin outputs (<= 4 columns) with a long K and few rows: the discriminators' last layers (Conv3d 512->1 k2,
 // Conv2d 256->1 k4; models/mocogan.py:88,158).  A 128x32 MFMA tile would run ~128 serial K slabs in a handful of
@@ -779,8 +814,12 @@ static int launch(IgemmArgs& A, bool vec, int max_mblk, bool double_buf, const S
     }
     if (sp.ksplit > 1) {
       GODE_LAUNCH_CHECK();
-      hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(gode_ceil_div(sp.positions, SPLITK_ROWS)), dim3(256), 0, st, A.work, A.out,
-                         A.stats, sp.positions, A.G.Ncols, sp.ksplit, A.epilogue);
+      if (A.G.Ncols % 4 == 0 && ((uintptr_t)A.work % 16) == 0 && ((uintptr_t)A.out % 16) == 0)
+        hipLaunchKernelGGL(igemm_splitk_reduce_vec_kernel, dim3(gode_ceil_div(sp.positions, SPLITK_ROWS), gode_ceil_div(A.G.Ncols, 64)),
+                           dim3(256), 0, st, A.work, A.out, A.stats, sp.positions, A.G.Ncols, sp.ksplit, A.epilogue);
+      else
+        hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(gode_ceil_div(sp.positions, SPLITK_ROWS)), dim3(256), 0, st, A.work, A.out,
+                           A.stats, sp.positions, A.G.Ncols, sp.ksplit, A.epilogue);
     }
   }
   else if (vec) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true>), grid, block, 0, st, A);

@@ -120,8 +120,7 @@ class ConvStack:
                 self.mean.append(None); self.invstd.append(None); self.scale.append(None); self.shift.append(None)
         self._ig_work = None    # split-K workspace shared by the plan's igemm ops (they run back to back)
         self._fwd = {}          # training flag -> Program
-        self._bwd = None
-        self._bwd_need_input = None
+        self._bwd = {}          # (need_input_grad, need_param_grad) -> Program (D steps and G steps alternate)
         self.g = None           # gradient buffers (lazy)
         self._param_ptrs = None
 
@@ -208,7 +207,7 @@ class ConvStack:
         """Programs hold raw parameter pointers; rebuild them if a module was moved/re-allocated."""
         ptrs = self.param_ptrs()
         if ptrs != self._param_ptrs:
-            self._fwd, self._bwd, self._param_ptrs = {}, None, ptrs
+            self._fwd, self._bwd, self._param_ptrs = {}, {}, ptrs
             self._all_igemm = []
 
     def weights_key(self):
@@ -341,13 +340,14 @@ class ConvStack:
                     b = L.BnBwdOp(g=dptr(self.g[l - 1]), y=dptr(self.y[l - 1]), M=M, C=Cc, act=sp.act)
                 patch.setdefault("bnb", []).append(b)
                 ops.append(b)
-        self.wg_work = torch.empty(max(wg_work, 1), **f32)
-        self.bn_work = torch.empty(max(bn_work, 1), **f32)
+        wg_buf = torch.empty(max(wg_work, 1), **f32)
+        bn_buf = torch.empty(max(bn_work, 1), **f32)
+        patch["keep"] = (wg_buf, bn_buf)      # owned by this program (several backward programs coexist)
         for _, w in patch["dw"]:
-            w.work = self.wg_work.data_ptr()
+            w.work = wg_buf.data_ptr()
         for b in patch.get("bnb", []):
             if b.mean:
-                b.work = self.bn_work.data_ptr()
+                b.work = bn_buf.data_ptr()
         patch["packs"] = bpacks
         self._attach_work([op for op in ops if isinstance(op, L.IgemmOp)])
         return L.Program(ops), patch
@@ -357,10 +357,9 @@ class ConvStack:
         Returns (flat parameter gradients or None, per-layer views list, input gradient buffer or None)."""
         self._refresh()
         key = (need_input_grad, need_param_grad)
-        if self._bwd is None or self._bwd_need_input != key:
-            self._bwd = self._build_bwd(need_input_grad, need_param_grad)
-            self._bwd_need_input = key
-        prog, patch = self._bwd
+        if key not in self._bwd:
+            self._bwd[key] = self._build_bwd(need_input_grad, need_param_grad)
+        prog, patch = self._bwd[key]
         self._run_stale_packs(patch["packs"], stream_ptr())
         self.g[-1].copy_(gout)
         if "tanh" in patch:
