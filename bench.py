@@ -36,9 +36,11 @@ def _sync_all(distributed):
     torch.cuda.synchronize()
 
 
-def _timed(fn, steps, warmup, distributed):
+def _timed(fn, steps, warmup, distributed, after_warmup=None):
     for _ in range(warmup):
         fn()
+    if after_warmup is not None:
+        after_warmup()
     _sync_all(distributed)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -173,7 +175,8 @@ def main():
         with torch.no_grad():
             gen.sample_videos(B)
 
-    dt = _timed(sample, a.steps, a.warmup, distributed)
+    # freeze_host_gc: keep Python's full-heap garbage-collection pass (75-100 ms) out of the loops (see its docstring)
+    dt = _timed(sample, a.steps, a.warmup, distributed, after_warmup=G.freeze_host_gc)
     vps = world * B * a.steps / dt
 
     # G / D step and whole-iteration milliseconds (synthetic real data resident on the GPU)

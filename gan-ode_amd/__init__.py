@@ -7,12 +7,12 @@ anything does, and there is no fallback path.
 from . import _lib
 from .modules import (Noise, ODEFunc, PatchImageDiscriminator, VideoDiscriminator, VideoGenerator,
                       VideoGeneratorMNIST, VideoGeneratorMNISTODE, VideoGeneratorMNISTODERNN)
-from .train import (FusedAdam, GanTrainer, bce_with_logits_const, build_mnist, build_ucf, host_cpu_quota,
-                    limit_host_threads, train_step)
+from .train import (FusedAdam, GanTrainer, bce_with_logits_const, build_mnist, build_ucf, freeze_host_gc,
+                    host_cpu_quota, limit_host_threads, train_step)
 
 __all__ = ["Noise", "ODEFunc", "PatchImageDiscriminator", "VideoDiscriminator", "VideoGenerator",
            "VideoGeneratorMNIST", "VideoGeneratorMNISTODE", "VideoGeneratorMNISTODERNN", "FusedAdam", "GanTrainer", "bce_with_logits_const",
-           "build_mnist", "build_ucf", "train_step", "host_cpu_quota", "limit_host_threads", "_lib"]
+           "build_mnist", "build_ucf", "train_step", "host_cpu_quota", "limit_host_threads", "freeze_host_gc", "_lib"]
 
 import os as _os
 

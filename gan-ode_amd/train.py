@@ -45,6 +45,17 @@ def limit_host_threads(n=None):
     return n
 
 
+def freeze_host_gc():
+    """One full-heap (generation-2) pass of Python's cyclic garbage collector over the heap that `import torch` and
+    the plans leave behind takes 75-100 ms, and the first one of a run lands after ~60 training iterations: one
+    iteration of 106 ms among 12.6 ms ones (scripts/diag_iter_values.py; the GPU drains and idles meanwhile).  Moving
+    the long-lived objects to the permanent generation after warm-up makes later passes walk only young objects.
+    GanTrainer calls this once after its second iteration; bench.py before its timed loops."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # loss
 # ------------------------------------------------------------------------------------------------------------------
@@ -209,7 +220,7 @@ class GanTrainer:
     """Owns the three networks and their optimisers; step() is one outer iteration of the reference loop."""
 
     def __init__(self, gen, dis_vid, dis_img, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5, d_iters=2,
-                 process_group=None, freeze_d_in_g_step=True):
+                 process_group=None, freeze_d_in_g_step=True, freeze_gc=True):
         self.gen, self.dis_vid, self.dis_img = gen, dis_vid, dis_img
         mk = lambda m: FusedAdam(m.parameters(), lr=lr, betas=betas, weight_decay=weight_decay)  # noqa: E731
         self.gen_opt, self.vid_opt, self.img_opt = mk(gen), mk(dis_vid), mk(dis_img)
@@ -217,6 +228,7 @@ class GanTrainer:
         self.freeze_d = freeze_d_in_g_step
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.buckets = {id(m): GradBucket(list(m.parameters())) for m in (gen, dis_vid, dis_img)}
+        self._iters, self._freeze_gc = 0, freeze_gc
 
     def _opt_step(self, model, opt):
         if self.world > 1:
@@ -284,6 +296,9 @@ class GanTrainer:
             li = self.d_image_step(real_imgs[i])
             lv = self.d_video_step(real_vids[i])
         lg = self.g_step(B)
+        self._iters += 1
+        if self._freeze_gc and self._iters == 2:     # every plan and program exists now
+            freeze_host_gc()
         return li, lv, lg
 
 
