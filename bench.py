@@ -86,7 +86,7 @@ def _kernel_roofline(gen, reps=30):
     dom = max(per_layer[1:4], key=lambda d: d["ms"])
     traffic = None   # HBM-side bytes per launch from the committed PMC passes (not collectable inside this process)
     try:
-        pm = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["per_launch"]
+        pm = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic_v3.json")))["per_launch"]
         traffic = pm[dom["layer"]]["traffic_bytes"]
     except Exception:
         pass

@@ -34,10 +34,11 @@ struct IgemmArgs {
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs in linear id order (id and id+8 share an XCD and its 4 MiB L2);
-// this is used for speed only.  xcd_mode 1 keeps all m-blocks of one (n-block, phase) "combo" on one XCD (its weight
-// panel stays L2-resident: layers whose packed weights exceed the L2), xcd_mode 2 keeps all combos of one m-block on
-// one XCD back to back (the gathered activation rows are fetched from HBM once: layers dominated by activation
-// traffic), 0 is the plain order.  Every mode is a bijection of [0, MB*NB*nphase).
+// this is used for locality only.  xcd_mode 1 keeps all m-blocks of one (n-block, phase) "combo" on one XCD (its weight
+// panel stays L2-resident), xcd_mode 2 keeps all combos of one m-block on one XCD back to back (the gathered
+// activation rows are fetched once), xcd_mode 3 additionally gives each XCD a contiguous run of m-blocks (halo rows
+// shared by neighbouring output rows hit the same L2; the default), 0 is the plain order.  Every mode is a bijection
+// of [0, MB*NB*nphase).
 __device__ __forceinline__ void igemm_block_id(const IgemmArgs& a, int& mblk, int& nblk, int& phase, int& split) {
   const int MB = a.MB, NC = a.NB * a.G.nphase;
   split = blockIdx.x / (MB * NC);
@@ -50,6 +51,9 @@ __device__ __forceinline__ void igemm_block_id(const IgemmArgs& a, int& mblk, in
   } else if (a.xcd_mode == 2) {
     const int x = id & 7, j = id >> 3;
     combo = j % NC; mblk = (j / NC) * 8 + x;
+  } else if (a.xcd_mode == 3) {          // like 2, but every XCD owns a CONTIGUOUS run of m-blocks: neighbouring output
+    const int x = id & 7, j = id >> 3;   // rows (which share input halo rows) hit the same L2
+    combo = j % NC; mblk = x * (MB >> 3) + j / NC;
   } else {
     mblk = id % MB; combo = id / MB;
   }
@@ -794,10 +798,18 @@ static int launch(IgemmArgs& A, bool vec, int max_mblk, bool double_buf, const S
     const int64_t wbytes = gode_pack_floats(A.G) * 4;
     const bool ok1 = (NC % 8 == 0) || (NC < 8 && 8 % NC == 0 && MB % (8 / NC) == 0);
     const bool ok2 = MB % 8 == 0;
-    int mode = (wbytes > (3 << 20) && ok1) ? 1 : (ok2 ? 2 : (ok1 ? 1 : 0));
+    // measured L2-miss (fabric) fetch per launch on the three decoder layers, forward / backward-data, raw FETCH_SIZE MB:
+    // mode 0: 45/95/411, 76/139/161;  mode 1: 203/230/338, 197/222/161;  mode 2: 68/73/46, 76/93/161;
+    // mode 3: 68/33/36, 60/89/154 -- at equal launch times (+-1.5 %), so the choice is made on traffic alone
+    // Mode 3 makes every XCD read the whole weight pack once; when 8 copies of it outweigh the gathered tensor 3:1
+    // (ConvT 512->256 forward: 8 x 8.4 MB vs 16.8 MB) the plain order, which spreads the panels, fetches less.
+    const int64_t images = (int64_t)A.out_numel / ((int64_t)A.G.Xd * A.G.Xh * A.G.Xw * A.G.Ncols);
+    const int64_t in_bytes = images * A.G.Gd * A.G.Gh * A.G.Gw * A.G.Cg * 4;
+    int mode = ok2 ? (wbytes * 8 < 3 * in_bytes ? 3 : 0) : 0;
     if (force == 0) mode = 0;
     if (force == 1 && ok1) mode = 1;
     if (force == 2 && ok2) mode = 2;
+    if (force == 3 && ok2) mode = 3;
     A.xcd_mode = mode;
     dim3 g1(MB * NC * sp.ksplit);
     const bool has_xf = A.scale != nullptr || A.act != GODE_ACT_NONE;
