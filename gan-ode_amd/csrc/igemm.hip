@@ -750,11 +750,79 @@ static int pick_tile_split_aware(const gode_conv_geom& g, const IgemmGeom& G, in
   return t;
 }
 
+// Tile and K-split of a FAST-path GEMM from a small cost model instead of thresholds.  All workgroups of a launch
+// carry equal work and the dispatcher deals them evenly, so the launch lasts as long as the busiest CU:
+//   time = ceil(workgroups / 256) * (fixed + slabs * cycles_per_slab(tile) / efficiency) [+ split-K reduce]
+// with the MFMA cycles of one 32-deep slab (64 per 32x32x2 instruction), the measured pipe efficiencies of the tiles
+// (two or more resident workgroups per CU overlap each other's barriers; a lone one cannot) and ~4k cycles of
+// prologue + epilogue.  Checked against measurements: ConvT 128->64 (4096 x 128x64) 314 us model / 297 us measured;
+// UCF video-D layer-2 dgrad 128x128 578 / 514 us, for which the model prefers 128x64 (436 us).
+static void choose_fast(const gode_igemm_op* op, const IgemmGeom& G, int* tile_out, SplitPlan* sp_out) {
+  const gode_conv_geom& g = op->g;
+  const int positions = g.N * G.Xd * G.Xh * G.Xw;
+  const double out_bytes = 4.0 * positions * G.Ncols;
+  int max_slabs = 0, min_slabs = 1 << 30;
+  bool even_phases = true;        // phases of unequal size leave early-exit workgroups in the grid: measured, a K split
+  for (int i = 0; i < G.nphase; ++i) {   // then gains nothing (video-D layer 3 dgrad: 101 us split 3 ways vs 64 us unsplit)
+    const int ns = G.ph[i].K >> 5;
+    if (ns > max_slabs) max_slabs = ns;
+    if (ns < min_slabs) min_slabs = ns;
+    even_phases = even_phases && G.ph[i].M == G.ph[0].M;
+  }
+  static const int tiles[4] = {TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32};
+  static const int ksplits[10] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+  double best = 1e300;
+  int best_tile = G.Ncols <= 32 ? TILE_128x32 : TILE_128x64, best_k = 1;
+  for (int ti = 0; ti < 4; ++ti) {
+    const int t = tiles[ti], bm = tile_bm(t), bn = tile_bn(t);
+    if (bn >= 2 * G.Ncols && bn > 32) continue;              // more than half of every tile would be padding
+    if (t == TILE_128x32 && G.Ncols > 32) continue;
+    const double cps = t == TILE_128x128 ? 4096.0 : (t == TILE_128x64 ? 2048.0 : 1024.0);
+    const int resident = t == TILE_128x128 ? 2 : (t == TILE_128x64 ? 3 : 4);
+    const double eff2 = (t == TILE_64x64 || t == TILE_128x32) ? 0.62 : 0.76;
+    int64_t tiles_n = 0;
+    for (int i = 0; i < G.nphase; ++i) tiles_n += (int64_t)gode_ceil_div(G.ph[i].M, bm) * gode_ceil_div(G.Ncols, bn);
+    for (int ki = 0; ki < 10; ++ki) {
+      const int k = ksplits[ki];
+      if (k > 1 && (min_slabs / k < 4 || out_bytes * k > 192e6 || min_slabs != max_slabs || !even_phases)) break;
+      const int64_t blocks = tiles_n * k;
+      const int64_t per_cu = (blocks + 255) / 256;
+      const int slabs = gode_ceil_div(max_slabs, k);
+      const double eff = (per_cu >= 2 && resident >= 2) ? eff2 : 0.8 * eff2;
+      double cyc = (double)per_cu * (4000.0 + slabs * cps / eff);
+      if (k > 1) cyc += 2.4e9 * (2.5e-6 + (k + 1) * out_bytes / 3e12);
+      if (cyc < best * 0.97) { best = cyc; best_tile = t; best_k = k; }   // 3 % hysteresis toward the earlier (larger) choice
+    }
+  }
+  *tile_out = best_tile;
+  sp_out->positions = positions;
+  sp_out->ksplit = 1; sp_out->slabs_per_split = 0;
+  if (best_k > 1) {
+    sp_out->slabs_per_split = gode_ceil_div(max_slabs, best_k);
+    sp_out->ksplit = gode_ceil_div(max_slabs, sp_out->slabs_per_split);
+  }
+}
+
 static int prepare(const gode_igemm_op* op, IgemmArgs* A, int* tile, int* max_mblk, int* rows, SplitPlan* sp) {
   int rc = gode_build_igemm_geom(op->g, op->dir, &A->G);
   if (rc) return rc;
+  static const char* menv = getenv("GODE_IGEMM_MODEL");
+  static const bool sweeping = getenv("GODE_IGEMM_SWEEP") != nullptr;     // calibration runs: GODE_IGEMM_FORCE="tile,k" is re-read per call
+  const char* fenv = sweeping ? getenv("GODE_IGEMM_FORCE") : nullptr;
+  int ftile = 0, fk = 0;
+  if (fenv && sscanf(fenv, "%d,%d", &ftile, &fk) == 2 && op->tile == 0 && fast_geometry(A->G) && A->G.Ncols > 4 &&
+      strides_allow_vec(op, A->G)) {
+    int max_slabs = 0;
+    for (int i = 0; i < A->G.nphase; ++i) if ((A->G.ph[i].K >> 5) > max_slabs) max_slabs = A->G.ph[i].K >> 5;
+    *tile = ftile;
+    sp->positions = op->g.N * A->G.Xd * A->G.Xh * A->G.Xw; sp->ksplit = 1; sp->slabs_per_split = 0;
+    if (fk > 1) { sp->slabs_per_split = gode_ceil_div(max_slabs, fk); sp->ksplit = gode_ceil_div(max_slabs, sp->slabs_per_split); }
+  } else if (op->tile == 0 && fast_geometry(A->G) && A->G.Ncols > 4 && strides_allow_vec(op, A->G) && (!menv || atoi(menv) != 0)) {
+    choose_fast(op, A->G, tile, sp);
+  } else {
   *tile = pick_tile_split_aware(op->g, A->G, op->tile);
   *sp = plan_split(op, A->G, *tile);
+  }
   const int bm = tile_bm(*tile);
   int r0 = 0, mx = 0;
   for (int i = 0; i < A->G.nphase; ++i) {
