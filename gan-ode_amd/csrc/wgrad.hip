@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(const WgradArgs a, int 
   const int ML = 256 / CL;                  // position lanes
   const int tid = threadIdx.x, cl = tid % CL, ml = tid / CL;
   const int Kt = a.Kt;
-  __shared__ float red[256][4];
+  __shared__ __attribute__((aligned(16))) float red[4][256][4];   // 16 KB: taps are combined four at a time
   const float nslope = a.act == GODE_ACT_RELU ? 0.f : (a.act == GODE_ACT_LRELU ? 0.2f : 1.f);
   const float xneg = a.xform_on_y ? 1.f : nslope, yneg = a.xform_on_y ? nslope : 1.f;
   const int m0 = blockIdx.x * chunk_thin;
@@ -402,22 +402,28 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(const WgradArgs a, int 
         }
       }
     }
-    // combine the position lanes: one tap at a time through LDS (fixed order)
+    // combine the position lanes through LDS (fixed order q = 0..ML-1): thread (tap j, channel lane c) sums its column
     float* dst = a.work + (int64_t)blockIdx.x * g.Co * Kt;
 #pragma unroll
-    for (int j = 0; j < THIN_MAXKT; ++j) {
-      if (j < Kt) {            // wave-uniform: every thread of the workgroup takes the same branch
+    for (int j0 = 0; j0 < THIN_MAXKT; j0 += 4) {
+      if (j0 < Kt) {           // wave-uniform
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) red[tid][e] = cok ? acc[j][e] : 0.f;
+        for (int jj = 0; jj < 4; ++jj)
+          if (j0 + jj < Kt) *reinterpret_cast<f32x4*>(red[jj][tid]) = cok ? acc[j0 + jj] : f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
-        if (tid < CL && cg + tid < C4) {
-          f32x4 s = {0.f, 0.f, 0.f, 0.f};
-          for (int q = 0; q < ML; ++q)
+        const int nj = Kt - j0 < 4 ? Kt - j0 : 4;
+        for (int i = tid; i < nj * CL; i += 256) {
+          const int jj = i / CL, c = i - jj * CL;
+          if (cg + c < C4) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < ML; ++q) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(red[jj][q * CL + c]);
+              s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+            }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s[e] += red[q * CL + tid][e];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) dst[(int64_t)((cg + tid) * 4 + e) * Kt + j] = s[e];
+            for (int e = 0; e < 4; ++e) dst[(int64_t)((cg + c) * 4 + e) * Kt + j0 + jj] = s[e];
+          }
         }
       }
     }
@@ -460,22 +466,29 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* work, fl
   }
 }
 
-// few outputs, many slabs (thin path): 64 outputs x 4 slab lanes per workgroup, fixed-order combine through LDS
+// few outputs, many slabs (thin path, up to 1024 slabs): 16 outputs x 16 slab lanes per workgroup -- each lane's chain
+// is splits/16 loads, 8 in flight (64 x 4 lanes meant 256 serial loads per thread: ~30 us of pure latency);
+// fixed-order combine through LDS
+#define RS_OUT 16
+#define RS_LANES 16
 __global__ void __launch_bounds__(256) wgrad_reduce_small_kernel(const float* work, float* dw, int Co, int Ci, int taps,
                                                                  int splits, const int32_t* co_perm, int accumulate) {
-  __shared__ double red[4][64];
+  __shared__ double red[RS_LANES][RS_OUT];
   const int Kt = Ci * taps, total = Co * Kt;
-  const int o = threadIdx.x & 63, ln = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + o;
+  const int o = threadIdx.x & (RS_OUT - 1), ln = threadIdx.x / RS_OUT;
+  const int i = blockIdx.x * RS_OUT + o;
   double sd = 0.0;
   if (i < total) {
-#pragma unroll 4
-    for (int zz = ln; zz < splits; zz += 4) sd += (double)work[(int64_t)zz * total + i];
+#pragma unroll 8
+    for (int zz = ln; zz < splits; zz += RS_LANES) sd += (double)work[(int64_t)zz * total + i];
   }
   red[ln][o] = sd;
   __syncthreads();
   if (ln == 0 && i < total) {
-    const float sv = (float)(red[0][o] + red[1][o] + red[2][o] + red[3][o]);
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < RS_LANES; ++q) tot += red[q][o];
+    const float sv = (float)tot;
     int co = i / Kt;
     const int j = i - co * Kt, tap = j / Ci, ci = j - tap * Ci;
     if (co_perm) { co = co_perm[co]; if (co < 0) return; }
@@ -517,7 +530,7 @@ static bool wg_thin(const gode_conv_geom& g) {
 }
 static int wg_thin_blocks(const gode_conv_geom& g) {
   const int64_t M = (int64_t)g.N * g.Do * g.Ho * g.Wo;
-  int64_t b = (M + 255) / 256;     // 16 positions per thread: enough workgroups to cover the gather latency
+  int64_t b = (M + 63) / 64;       // ~4 positions per thread (the per-position gather chain is serial), up to 1024 workgroups
   return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
 }
 static int wg_splits(const gode_wgrad_op* op) {
@@ -588,7 +601,7 @@ extern "C" int gode_wgrad(const gode_wgrad_op* op, void* stream) {
   if (rc) return rc;
   const int64_t total = (int64_t)g.Co * A.Kt;
   if (total <= 8192 && splits >= 16) {
-    hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, st, op->work, op->dw, g.Co,
+    hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((int)((total + RS_OUT - 1) / RS_OUT)), dim3(256), 0, st, op->work, op->dw, g.Co,
                        g.Ci, A.taps, splits, op->co_perm, op->accumulate);
     GODE_LAUNCH_CHECK();
     return 0;
