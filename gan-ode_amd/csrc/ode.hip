@@ -218,8 +218,10 @@ __global__ void __launch_bounds__(64) ode_bwd_kernel(const gode_ode_bwd_op a) {
   }
 }
 
-__global__ void __launch_bounds__(256) ode_bwd_reduce_kernel(const float* work, float* grads, int nblk, int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+// `first`: entries below it are not touched (no pre-net: only the ODEFunc block [OFF_W1, NPARAM) exists, and `grads`
+// may then point 2128 floats before a caller-owned region that holds just that block)
+__global__ void __launch_bounds__(256) ode_bwd_reduce_kernel(const float* work, float* grads, int nblk, int accumulate, int first) {
+  const int i = first + blockIdx.x * 256 + threadIdx.x;
   if (i >= GODE_ODE_NPARAM) return;
   float s = 0.f;
   for (int b = 0; b < nblk; ++b) s += work[(int64_t)b * GODE_ODE_NPARAM + i];
@@ -238,8 +240,9 @@ extern "C" int gode_ode_bwd(const gode_ode_bwd_op* op, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ode_bwd_kernel, dim3(nblk), dim3(64), 0, st, *op);
   GODE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ode_bwd_reduce_kernel, dim3((GODE_ODE_NPARAM + 255) / 256), dim3(256), 0, st, op->work, op->grads,
-                     nblk, op->accumulate);
+  const int first = op->prenet ? 0 : OFF_W1;
+  hipLaunchKernelGGL(ode_bwd_reduce_kernel, dim3((GODE_ODE_NPARAM - first + 255) / 256), dim3(256), 0, st, op->work, op->grads,
+                     nblk, op->accumulate, first);
   GODE_LAUNCH_CHECK();
   return 0;
 }

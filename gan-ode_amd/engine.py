@@ -352,9 +352,21 @@ class ConvStack:
         self._attach_work([op for op in ops if isinstance(op, L.IgemmOp)])
         return L.Program(ops), patch
 
-    def backward(self, gout: torch.Tensor, need_input_grad: bool, need_param_grad: bool = True):
+    def _patch_user_input(self, patch):
+        if self.x_in is None and "wgrad0" in patch:
+            w0 = patch["wgrad0"]
+            tgt = "x" if self.specs[0].fwd_dir == L.FPROP else "y"
+            if tgt != "x":
+                raise RuntimeError("caller-owned input is only supported for Conv (FPROP) stacks")
+            w0.x = self._x_user.data_ptr()
+            for i in range(5):
+                w0.xs[i] = self._x_strides[i]
+
+    def backward(self, gout: torch.Tensor, need_input_grad: bool, need_param_grad: bool = True, into=None):
         """gout: gradient wrt the (activated) output, any strides, logical dims = self.out_dims.
-        Returns (flat parameter gradients or None, per-layer views list, input gradient buffer or None)."""
+        Returns (flat parameter gradients or None, per-layer views list, input gradient buffer or None).
+        into: optional per-layer [(weight_grad, gamma_grad, beta_grad, accumulate)] -- the kernels then write (or
+        add to) those caller-owned tensors directly and (None, None, g_in) is returned."""
         self._refresh()
         key = (need_input_grad, need_param_grad)
         if key not in self._bwd:
@@ -364,12 +376,25 @@ class ConvStack:
         self.g[-1].copy_(gout)
         if "tanh" in patch:
             patch["tanh"].y = self.out.data_ptr()
-        flat = torch.empty(self.n_grad_floats() if need_param_grad else 1, dtype=torch.float32, device=self.device)
-        views, off = [], 0
         if not need_param_grad:
             prog.run(stream_ptr())
             self.busy = False
             return None, None, (self.g_in if need_input_grad else None)
+        if into is not None:
+            per = {l: t for l, t in enumerate(into)}
+            for l, w in patch["dw"]:
+                w.dw = per[l][0].data_ptr()
+                w.accumulate = 1 if per[l][3] else 0
+            for l, b in patch["dgamma"]:
+                b.dgamma = per[l][1].data_ptr()
+                b.dbeta = per[l][2].data_ptr()
+                b.accumulate = 1 if per[l][3] else 0
+            self._patch_user_input(patch)
+            prog.run(stream_ptr())
+            self.busy = False
+            return None, None, (self.g_in if need_input_grad else None)
+        flat = torch.empty(self.n_grad_floats(), dtype=torch.float32, device=self.device)
+        views, off = [], 0
         per_layer = {}
         for l, p in enumerate(self.params):
             n = p.weight.numel()
@@ -383,17 +408,12 @@ class ConvStack:
             views.append((wv, gv, bv))
         for l, w in patch["dw"]:
             w.dw = per_layer[l][0].data_ptr()
+            w.accumulate = 0
         for l, b in patch["dgamma"]:
             b.dgamma = per_layer[l][1].data_ptr()
             b.dbeta = per_layer[l][2].data_ptr()
-        if self.x_in is None and "wgrad0" in patch:
-            w0 = patch["wgrad0"]
-            tgt = "x" if self.specs[0].fwd_dir == L.FPROP else "y"
-            if tgt != "x":
-                raise RuntimeError("caller-owned input is only supported for Conv (FPROP) stacks")
-            w0.x = self._x_user.data_ptr()
-            for i in range(5):
-                w0.xs[i] = self._x_strides[i]
+            b.accumulate = 0
+        self._patch_user_input(patch)
         prog.run(stream_ptr())
         self.busy = False
         return flat, views, (self.g_in if need_input_grad else None)

@@ -144,11 +144,33 @@ class _GenPlan:
         self.busy = keep
         return out
 
-    def backward(self, gout):
+    def backward(self, gout, arena=None):
+        if arena is not None:
+            # gradients go straight into the trainer's arena (first writer of a step stores, later ones add)
+            into = []
+            for lp in self.gen._decoder_params():
+                wt, acc = arena.target(lp.weight)
+                gt = bt = None
+                if lp.gamma is not None:
+                    gt, _ = arena.target(lp.gamma)
+                    bt, _ = arena.target(lp.beta)
+                into.append((wt, gt, bt, acc))
+            _, _, gz = self.stack.backward(gout, need_input_grad=True, into=into)
+            ode = [q for q in self._ode_params() if q is not None]
+            tgt = [arena.target(q) for q in ode]
+            base, acc = tgt[0]
+            off = base.data_ptr() - (0 if self._ode_ptrs[0] is not None else 2128 * 4)   # kernel offsets start at Wa
+            self.bwd_op.gz = gz.data_ptr()
+            self.bwd_op.grads = off
+            self.bwd_op.accumulate = 1 if acc else 0
+            L.run_one(self.bwd_op, stream_ptr())
+            self.busy = False
+            return None, None
         flat, views, gz = self.stack.backward(gout, need_input_grad=True)
         grads = torch.empty(L.ODE_NPARAM, dtype=torch.float32, device=self.device)
         self.bwd_op.gz = gz.data_ptr()
         self.bwd_op.grads = grads.data_ptr()
+        self.bwd_op.accumulate = 0
         L.run_one(self.bwd_op, stream_ptr())
         self.busy = False
         offs = [(0, 1024, (64, 16)), (1024, 64, (64,)), (1088, 1024, (16, 64)), (2112, 16, (16,)),
@@ -170,6 +192,10 @@ class _GenFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         plan = ctx.plan
+        arena = getattr(plan.gen, "_gode_arena", None)
+        if arena is not None and arena.active:
+            plan.backward(gout, arena)
+            return (None,) * (7 + ctx.n_params)
         views, motion = plan.backward(gout)
         grads = []
         for wv, gv, bv in views:
@@ -285,6 +311,12 @@ class VideoGenerator(nn.Module):
         if hasattr(self, "_pool"):
             self._pool.clear()   # parameter storage may have moved
         return r
+
+    _gode_direct_grads = True      # the backward kernels can write into a trainer-owned GradArena
+
+    def _arena_tail(self):
+        """Pre-net + ODEFunc tensors in the adjoint kernel's output order (they must be contiguous in the arena)."""
+        return self._param_list()[1]
 
     # -- host-side latent draws: RNG call order is part of the contract ---------------------------------------
     def _draw(self, num_samples, video_len):
@@ -415,6 +447,9 @@ class VideoGeneratorMNISTODERNN(VideoGeneratorMNIST):
     a GPU; here it is always drawn from the global torch CPU generator in the same order and copied to the device, so
     that runs are comparable with the CPU oracle at identical seeds ("ROCm .cuda() semantics")."""
 
+    _gode_direct_grads = False     # its plan keeps the stock autograd accumulation
+
+
     _plan_cls = _RnnGenPlan
     ode_rtol, ode_atol = 1e-7, 1e-9
     adjoint_substeps = 32
@@ -474,35 +509,51 @@ class Noise(nn.Module):
 
 class _DiscFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, strides, training, keep, x, *params):
+    def forward(ctx, plan, strides, training, keep, arena, x, *params):
         out = plan.forward(training, x=x, x_strides=strides)
         plan.busy = keep
         ctx.plan = plan
         ctx.x_shape = x.shape
+        ctx.arena = arena
         return out
 
     @staticmethod
     def backward(ctx, gout):
         plan = ctx.plan
-        need_x = ctx.needs_input_grad[4]
-        need_p = any(ctx.needs_input_grad[5:])
-        flat, views, g_in = plan.backward(gout, need_input_grad=need_x, need_param_grad=need_p)
+        need_x = ctx.needs_input_grad[5]
+        need_p = any(ctx.needs_input_grad[6:])
+        arena = ctx.arena
+        into = None
+        if need_p and arena is not None and arena.active:
+            into = []
+            for lp in plan.params:
+                wt, acc = arena.target(lp.weight)
+                gt = bt = None
+                if lp.gamma is not None:
+                    gt, _ = arena.target(lp.gamma)
+                    bt, _ = arena.target(lp.beta)
+                into.append((wt, gt, bt, acc))
+        flat, views, g_in = plan.backward(gout, need_input_grad=need_x, need_param_grad=need_p, into=into)
         grads = []
-        if need_p:
+        if into is not None:
+            grads = [None] * (len(ctx.needs_input_grad) - 6)
+        elif need_p:
             for wv, gv, bv in views:
                 grads.append(wv)
                 if gv is not None:
                     grads += [gv, bv]
         else:
-            grads = [None] * (len(ctx.needs_input_grad) - 5)
+            grads = [None] * (len(ctx.needs_input_grad) - 6)
         gx = None
         if need_x:
             g = g_in.clone()                               # [N, D, H, W, C] channels-last (plan buffer is reused)
             gx = g.permute(0, 4, 1, 2, 3) if len(ctx.x_shape) == 5 else g[:, 0].permute(0, 3, 1, 2)
-        return (None, None, None, None, gx, *grads)
+        return (None, None, None, None, None, gx, *grads)
 
 
 class _DiscBase(nn.Module):
+    _gode_direct_grads = True
+
     def _specs(self, x_shape):
         raise NotImplementedError
 
@@ -545,7 +596,7 @@ class _DiscBase(nn.Module):
             if p.gamma is not None:
                 params += [p.gamma, p.beta]
         keep = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
-        out = _DiscFn.apply(plan, strides, self.training, keep, x, *params)      # [B, Do, Ho, Wo, 1]
+        out = _DiscFn.apply(plan, strides, self.training, keep, getattr(self, "_gode_arena", None), x, *params)      # [B, Do, Ho, Wo, 1]
         h = out.permute(0, 4, 1, 2, 3)
         if input.dim() == 4:
             h = h[:, :, 0]

@@ -201,6 +201,46 @@ class GradBucket:
         return out
 
 
+class GradArena:
+    """One flat fp32 gradient buffer per network, written by the backward kernels themselves: the first weight-gradient
+    / BatchNorm-gradient / adjoint kernel that produces a parameter's gradient in a step stores it (and `p.grad`
+    becomes a view of the arena), later ones (the second discriminator pass, the image path of the generator) add in
+    place.  Replaces autograd's AccumulateGrad adds (64 small launches per iteration) and, under data parallelism,
+    the pack-into-bucket copies: the arena IS the all-reduce bucket.  `order`: parameters in arena order (the
+    generator puts its pre-net + ODEFunc tensors last, in the adjoint kernel's output order)."""
+
+    def __init__(self, order: Sequence[torch.nn.Parameter]):
+        self.params = list(order)
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views, off = {}, 0
+        for p in self.params:
+            self.views[p] = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.written = set()
+        self.active = False
+
+    def begin(self):
+        """Start of an optimiser step (replaces zero_grad): every .grad is dropped, nothing is written yet."""
+        for p in self.params:
+            p.grad = None
+        self.written.clear()
+        self.active = True
+
+    def end(self):
+        self.active = False
+
+    def target(self, p):
+        """-> (tensor the kernel writes to, accumulate?) and binds p.grad to it on first use."""
+        v = self.views[p]
+        acc = p in self.written
+        if not acc:
+            self.written.add(p)
+            p.grad = v
+        return v, acc
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # the iteration
 # ------------------------------------------------------------------------------------------------------------------
@@ -220,7 +260,7 @@ class GanTrainer:
     """Owns the three networks and their optimisers; step() is one outer iteration of the reference loop."""
 
     def __init__(self, gen, dis_vid, dis_img, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5, d_iters=2,
-                 process_group=None, freeze_d_in_g_step=True, freeze_gc=True):
+                 process_group=None, freeze_d_in_g_step=True, freeze_gc=True, direct_grads=True):
         self.gen, self.dis_vid, self.dis_img = gen, dis_vid, dis_img
         mk = lambda m: FusedAdam(m.parameters(), lr=lr, betas=betas, weight_decay=weight_decay)  # noqa: E731
         self.gen_opt, self.vid_opt, self.img_opt = mk(gen), mk(dis_vid), mk(dis_img)
@@ -229,8 +269,34 @@ class GanTrainer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.buckets = {id(m): GradBucket(list(m.parameters())) for m in (gen, dis_vid, dis_img)}
         self._iters, self._freeze_gc = 0, freeze_gc
+        # direct_grads: backward kernels write into a per-network GradArena (see its docstring); networks without
+        # the hook (the ODE-RNN generator) and CPU tensors keep the stock autograd accumulation
+        self.arenas = {}
+        if direct_grads:
+            for m in (gen, dis_vid, dis_img):
+                ps = list(m.parameters())
+                if ps and ps[0].is_cuda and getattr(m, "_gode_direct_grads", False):
+                    tail = m._arena_tail() if hasattr(m, "_arena_tail") else []
+                    ids = {id(p) for p in tail}
+                    arena = GradArena([p for p in ps if id(p) not in ids] + tail)
+                    self.arenas[id(m)] = arena
+                    m._gode_arena = arena
+
+    def _begin(self, model, opt):
+        a = self.arenas.get(id(model))
+        if a is not None:
+            a.begin()
+        else:
+            opt.zero_grad()
 
     def _opt_step(self, model, opt):
+        a = self.arenas.get(id(model))
+        if a is not None:
+            a.end()
+            if self.world > 1:       # the arena is the bucket: one collective, no packing copies
+                dist.all_reduce(a.flat, op=dist.ReduceOp.SUM, group=self.group)
+            opt.step(gscale=1.0 / self.world)
+            return
         if self.world > 1:
             b = self.buckets[id(model)]
             b.gather()
@@ -241,7 +307,7 @@ class GanTrainer:
 
     def d_image_step(self, real_img):
         B = real_img.shape[0]
-        self.img_opt.zero_grad()
+        self._begin(self.dis_img, self.img_opt)
         pr, _ = self.dis_img(real_img)
         with torch.no_grad():
             fake, _ = self.gen.sample_images(B)
@@ -253,7 +319,7 @@ class GanTrainer:
 
     def d_video_step(self, real_vid):
         B = real_vid.shape[0]
-        self.vid_opt.zero_grad()
+        self._begin(self.dis_vid, self.vid_opt)
         pr, _ = self.dis_vid(real_vid.transpose(1, 2))          # [B,T,C,H,W] -> [B,C,T,H,W] view, read in place
         with torch.no_grad():
             fake, _ = self.gen.sample_videos(B)
@@ -264,7 +330,7 @@ class GanTrainer:
         return loss.detach()
 
     def g_step(self, B):
-        self.gen_opt.zero_grad()
+        self._begin(self.gen, self.gen_opt)
         frozen = []
         if self.freeze_d:
             # the reference lets this backward also fill the discriminators' .grad, which the next zero_grad()

@@ -294,7 +294,7 @@ def test_ode_golden_fixture_and_row_selection():
     assert rel_err(traj.cpu().transpose(0, 1), g["sol"]) < TOL
     gz = torch.zeros(N * T, 72, device="cuda")
     gz.view(N, T, 72)[:, :, :16] = torch.from_numpy(g["grad_sol"]).transpose(0, 1).cuda()
-    grads = torch.empty(L.ODE_NPARAM, device="cuda")
+    grads = torch.full((L.ODE_NPARAM,), 7.5, device="cuda")
     work = torch.empty(L.lib().gode_ode_bwd_work_size(N), device="cuda")
     bop = L.OdeBwdOp(p=op, x=x.data_ptr(), traj=traj.data_ptr(), dt=dt.data_ptr(), sel_t=None, gz=gz.data_ptr(),
                      work=work.data_ptr(), grads=grads.data_ptr(), N=N, T=T, substeps=1, prenet=0, accumulate=0, zcols=72)
@@ -302,7 +302,7 @@ def test_ode_golden_fixture_and_row_selection():
     gg = grads.cpu()
     for k, o, n in (("fn.0.weight", 2128, 256), ("fn.0.bias", 2384, 16), ("fn.2.weight", 2400, 256), ("fn.2.bias", 2656, 16)):
         assert rel_err(gg[o:o + n].view(g[f"g/{k}"].shape), g[f"g/{k}"]) < 2e-4, k
-    assert float(gg[:2128].abs().max()) == 0.0
+    assert bool((gg[:2128] == 7.5).all())     # no pre-net: its block of the gradient vector is never touched
     # row selection: row n holds time sel[n]
     sel = torch.tensor([(3 * i) % T for i in range(N)], dtype=torch.int32).cuda()
     z2 = torch.zeros(N, 72, device="cuda")

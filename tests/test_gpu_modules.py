@@ -476,3 +476,35 @@ def test_data_parallel_step_path_on_one_rank_nccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_direct_gradient_arena_is_bitwise_the_autograd_accumulation():
+    """GanTrainer(direct_grads=True): the backward kernels store / add parameter gradients straight into a per-network
+    arena (p.grad = view) instead of returning them to autograd, which would add the two passes of a step with one
+    elementwise kernel per tensor.  Same kernels, same operands, one fp32 add either way -> identical bits."""
+    g = golden("train_mnist_tiny.npz")
+    s = int(g["seed"])
+    runs = []
+    for direct in (True, False):
+        gen, dv, di = G.build_mnist(ngf=8, ndf=8)
+        for m, p in ((gen, "gen"), (dv, "vid"), (di, "img")):
+            load_sd(m, g, f"w0/{p}")
+            m.cuda()
+        tr = G.GanTrainer(gen, dv, di, direct_grads=direct)
+        assert bool(tr.arenas) == direct
+        losses = []
+        for it in range(2):
+            imgs = [_f32(g[f"real_img/{it}/{i}"]).cuda() for i in range(2)]
+            vids = [_f32(g[f"real_vid/{it}/{i}"]).cuda() for i in range(2)]
+            seed_all(s + 1 + it)
+            losses.append([float(v) for v in tr.step(imgs, vids)])
+        if direct:      # gradients live in the arena; the unused GRU cell never received one
+            assert gen.main[0].weight.grad.data_ptr() == tr.arenas[id(gen)].views[gen.main[0].weight].data_ptr()
+            assert gen.recurrent.weight_ih.grad is None
+        runs.append((losses, [p.detach().clone() for m in (gen, dv, di) for p in m.parameters()],
+                     [p.grad.clone() for m in (gen,) for p in m.parameters() if p.grad is not None]))
+    assert runs[0][0] == runs[1][0]
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b)
+    for a, b in zip(runs[0][2], runs[1][2]):
+        assert torch.equal(a, b)
