@@ -61,14 +61,15 @@ class OdeParams(C.Structure):
 
 class OdeFwdOp(C.Structure):
     _fields_ = [("p", OdeParams), ("x", ptr), ("content", ptr), ("dt", ptr), ("sel_t", ptr), ("z", ptr),
-                ("traj", ptr), ("N", i32), ("T", i32), ("substeps", i32), ("prenet", i32), ("zcols", i32), ("pad_", i32)]
+                ("traj", ptr), ("N", i32), ("T", i32), ("substeps", i32), ("prenet", i32), ("zcols", i32), ("G", i32),
+                ("grid_dt", ptr), ("emit_at", ptr), ("emit_w", ptr)]
     KIND = OP_ODE_FWD
 
 
 class OdeBwdOp(C.Structure):
     _fields_ = [("p", OdeParams), ("x", ptr), ("traj", ptr), ("dt", ptr), ("sel_t", ptr), ("gz", ptr),
                 ("work", ptr), ("grads", ptr), ("N", i32), ("T", i32), ("substeps", i32), ("prenet", i32),
-                ("accumulate", i32), ("zcols", i32)]
+                ("accumulate", i32), ("zcols", i32), ("bstep_off", ptr), ("bstep_dt", ptr)]
     KIND = OP_ODE_BWD
 
 

@@ -68,6 +68,27 @@ __global__ void __launch_bounds__(64) ode_fwd_kernel(const gode_ode_fwd_op a) {
   };
   emit(0);
   const float third = 1.0f / 3.0f;
+  if (a.grid_dt != nullptr) {
+    // solver grid != output times: integrate step by step, emit every output whose time falls in the step just taken
+    int jo = 1;
+    for (int i = 0; i < a.G; ++i) {
+      const float dt = a.grid_dt[i];
+      const f32x4 y0 = y;
+      const f32x4 k1 = f(y);
+      const f32x4 k2 = f(y + dt * k1 * third);
+      const f32x4 k3 = f(y + dt * (k2 - k1 * third));
+      const f32x4 k4 = f(y + dt * (k1 - k2 + k3));
+      const f32x4 y1 = y0 + (k1 + 3.f * (k2 + k3) + k4) * dt * 0.125f;
+      while (jo < T && a.emit_at[jo] == i) {
+        const float w = a.emit_w[jo];
+        y = w == 1.f ? y1 : (w == 0.f ? y0 : y0 + w * (y1 - y0));
+        emit(jo);
+        ++jo;
+      }
+      y = y1;
+    }
+    return;
+  }
   for (int j = 0; j + 1 < T; ++j) {
     const float dt = a.dt[j] / (float)a.substeps;
     for (int ss = 0; ss < a.substeps; ++ss) {
@@ -84,6 +105,7 @@ __global__ void __launch_bounds__(64) ode_fwd_kernel(const gode_ode_fwd_op a) {
 
 extern "C" int gode_ode_fwd(const gode_ode_fwd_op* op, void* stream) {
   if (!op || !op->x || !op->z || !op->dt || op->N <= 0 || op->T < 1 || op->substeps < 1) return GODE_E_ARG;
+  if (op->grid_dt && (!op->emit_at || !op->emit_w || op->G < 1)) return GODE_E_ARG;
   if (op->zcols < 68 || op->zcols % 4 != 0) return GODE_E_ARG;
   if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2) return GODE_E_ARG;
   if (op->prenet && (!op->p.Wa || !op->p.ba || !op->p.Wb || !op->p.bb)) return GODE_E_ARG;
@@ -155,8 +177,11 @@ __global__ void __launch_bounds__(64) ode_bwd_kernel(const gode_ode_bwd_op a) {
   const float third = 1.0f / 3.0f;
   for (int i = T - 1; i >= 1; --i) {
     f32x4 y = valid ? ld4(a.traj + ((int64_t)n * T + i) * 16 + 4 * g) : zero4();
-    const float dt = a.dt[i - 1] / (float)a.substeps;
-    for (int ss = 0; ss < a.substeps; ++ss) {
+    const int s0 = a.bstep_off ? a.bstep_off[i - 1] : 0;
+    const int ns = a.bstep_off ? a.bstep_off[i] - s0 : a.substeps;
+    const float dt_eq = a.dt[i - 1] / (float)a.substeps;
+    for (int ss = 0; ss < ns; ++ss) {
+      const float dt = a.bstep_off ? a.bstep_dt[s0 + ss] : dt_eq;
       stage(y, adj, dt * 0.125f);
       const f32x4 ky1 = ky, ka1 = ka;
       stage(y + dt * ky1 * third, adj + dt * ka1 * third, 3.f * dt * 0.125f);
@@ -236,6 +261,7 @@ extern "C" int gode_ode_bwd(const gode_ode_bwd_op* op, void* stream) {
   if (op->zcols < 16 || op->zcols % 4 != 0) return GODE_E_ARG;
   if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2) return GODE_E_ARG;
   if (op->prenet && (!op->x || !op->p.Wa || !op->p.ba || !op->p.Wb || !op->p.bb)) return GODE_E_ARG;
+  if ((op->bstep_off == nullptr) != (op->bstep_dt == nullptr)) return GODE_E_ARG;
   const int nblk = (op->N + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ode_bwd_kernel, dim3(nblk), dim3(64), 0, st, *op);

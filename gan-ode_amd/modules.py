@@ -108,12 +108,50 @@ class _GenPlan:
         f = g.ode_fn.fn
         return pre + (f[0].weight, f[0].bias, f[2].weight, f[2].bias)
 
+    def _solver_grid(self, step_size):
+        """torchdiffeq options={'step_size': h} (FixedGridODESolver): the solver walks its own grid
+        arange(niters)*h + t0 (last point clamped to t_end) and interpolates the requested outputs linearly; the
+        adjoint pass solves every output interval on the grid built the same way for the reversed span.  All
+        arithmetic below is fp32 torch on the host, operation for operation what torchdiffeq executes, so the
+        device gets bit-identical step sizes and interpolation weights."""
+        T = self.T
+        t = torch.linspace(0, 1, T).float()
+
+        def grid_of(tt):
+            start, end = tt[0], tt[-1]
+            niters = int(torch.ceil((end - start) / step_size + 1).item())
+            gr = torch.arange(0, niters, dtype=tt.dtype) * step_size + start
+            gr[-1] = end
+            return gr
+
+        gr = grid_of(t)
+        gdt = gr[1:] - gr[:-1]
+        emit_at = torch.full((T,), -1, dtype=torch.int32)
+        emit_w = torch.zeros(T, dtype=torch.float32)
+        j = 1
+        for i in range(len(gr) - 1):
+            a, b = gr[i], gr[i + 1]
+            while j < T and bool(b >= t[j]):
+                emit_at[j] = i
+                emit_w[j] = 0.0 if bool(t[j] == a) else (1.0 if bool(t[j] == b) else (t[j] - a) / (b - a))
+                j += 1
+        assert j == T
+        off, steps = [0], []
+        for i in range(1, T):                      # adjoint of output interval i -> i-1: reversed span, t -> -t
+            rg = grid_of(-t[i - 1:i + 1].flip(0))
+            d = rg[1:] - rg[:-1]
+            steps.append(d)
+            off.append(off[-1] + len(d))
+        dev = self.device
+        return dict(G=len(gdt), grid_dt=gdt.to(dev), emit_at=emit_at.to(dev), emit_w=emit_w.to(dev),
+                    bstep_off=torch.tensor(off, dtype=torch.int32).to(dev), bstep_dt=torch.cat(steps).to(dev))
+
     def _programs(self):
         ps = self._ode_params()
-        ptrs = tuple(dptr(p) for p in ps)
+        ptrs = tuple(dptr(p) for p in ps) + (self.gen.ode_step_size,)
         if ptrs != self._ode_ptrs:
             self._ode_ptrs = ptrs
-            op = L.OdeParams(*ptrs)
+            op = L.OdeParams(*ptrs[:8])
             prenet = 0 if ps[0] is None else 1
             self.fwd_op = L.OdeFwdOp(p=op, x=dptr(self.x), content=dptr(self.content), dt=dptr(self.dt),
                                      sel_t=dptr(self.sel), z=dptr(self.stack.x_in), traj=dptr(self.traj), N=self.n,
@@ -121,6 +159,12 @@ class _GenPlan:
             self.bwd_op = L.OdeBwdOp(p=op, x=dptr(self.x), traj=dptr(self.traj), dt=dptr(self.dt),
                                      sel_t=dptr(self.sel), gz=None, work=dptr(self.ode_work), grads=None, N=self.n,
                                      T=self.T, substeps=self.gen.ode_substeps, prenet=prenet, accumulate=0, zcols=Z_COLS)
+            self._grid = None
+            if self.gen.ode_step_size is not None and self.T > 1:
+                gd = self._grid = self._solver_grid(float(self.gen.ode_step_size))
+                self.fwd_op.G = gd["G"]
+                self.fwd_op.grid_dt, self.fwd_op.emit_at, self.fwd_op.emit_w = dptr(gd["grid_dt"]), dptr(gd["emit_at"]), dptr(gd["emit_w"])
+                self.bwd_op.bstep_off, self.bwd_op.bstep_dt = dptr(gd["bstep_off"]), dptr(gd["bstep_dt"])
             self.fwd_prog = L.Program([self.fwd_op])
         self.fwd_op.substeps = self.bwd_op.substeps = self.gen.ode_substeps
 
@@ -225,6 +269,7 @@ class VideoGenerator(nn.Module):
         self.n_channels, self.dim_z_content, self.dim_z_category = n_channels, dim_z_content, dim_z_category
         self.dim_z_motion, self.video_length, self.ngf = dim_z_motion, video_length, ngf
         self.ode_substeps = 1
+        self.ode_step_size = None    # = torchdiffeq options={'step_size': h}; None: the reference's call (grid = outputs)
         dim_z = dim_z_motion + dim_z_category + dim_z_content
         # construction order == the reference's, so that a given torch seed yields the same initial weights
         self.recurrent = nn.GRUCell(dim_z_motion, dim_z_motion)       # models/mocogan.py:198 (unused by ODE path)

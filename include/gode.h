@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GODE_VERSION 100
+#define GODE_VERSION 101
 
 enum { GODE_OK = 0, GODE_E_ARG = -1, GODE_E_SHAPE = -2, GODE_E_KIND = -3 };
 enum { GODE_ACT_NONE = 0, GODE_ACT_RELU = 1, GODE_ACT_LRELU = 2,              /* LeakyReLU slope is 0.2 */
@@ -145,7 +145,12 @@ typedef struct gode_ode_fwd_op {
   gode_ode_params p;
   const float* x; const float* content; const float* dt; const int32_t* sel_t;
   float* z; float* traj; int32_t N, T, substeps, prenet; /* prenet==0: linear=False (nn.Identity) */
-  int32_t zcols, pad_;
+  int32_t zcols, G;
+  /* optional solver grid (torchdiffeq options={'step_size': h}: FixedGridODESolver integrates on its own grid and
+   * interpolates the outputs linearly).  grid_dt[G] = step sizes of the grid; output j >= 1 is produced after grid
+   * step emit_at[j] as y0 + emit_w[j]*(y1 - y0) (emit_w == 1: y1 itself).  grid_dt == NULL: the grid is the output
+   * times (dt[T-1], `substeps` equal sub-steps each) -- the reference's own call. */
+  const float* grid_dt; const int32_t* emit_at; const float* emit_w;
 } gode_ode_fwd_op;
 int gode_ode_fwd(const gode_ode_fwd_op* op, void* stream);
 /* adjoint backward (torchdiffeq odeint_adjoint semantics: per output interval ONE reverse-time RK4(3/8) step of
@@ -157,6 +162,10 @@ typedef struct gode_ode_bwd_op {
   gode_ode_params p;
   const float* x; const float* traj; const float* dt; const int32_t* sel_t; const float* gz;
   float* work; float* grads; int32_t N, T, substeps, prenet, accumulate, zcols;
+  /* optional per-interval reverse step lists (same option: the adjoint solve of output interval j -> j-1 runs on the
+   * grid torchdiffeq builds for the reversed span): steps bstep_dt[bstep_off[j-1] .. bstep_off[j]) for j = 1..T-1.
+   * NULL: `substeps` equal steps of dt[j-1]/substeps. */
+  const int32_t* bstep_off; const float* bstep_dt;
 } gode_ode_bwd_op;
 int gode_ode_bwd(const gode_ode_bwd_op* op, void* stream);
 int64_t gode_ode_bwd_work_size(int32_t N);
