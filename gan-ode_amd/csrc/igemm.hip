@@ -639,13 +639,15 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce_vec_kernel(const floa
 // Conv2d 256->1 k4; models/mocogan.py:88,158).  A 128x32 MFMA tile would run ~128 serial K slabs in a handful of
 // workgroups; here one wave owns one output position, its 64 lanes stride over K with float4 gathers and the
 // partial dot products are combined with wave shuffles.
-struct DotArgs { IgemmArgs a; FastDiv dCg; };
-
+struct DotArgs { IgemmArgs a; FastDiv dCg; int32_t per_block; };   // per_block: 4 = one position per wave; 1 = the four
+                                                                  // waves of a workgroup split the K of ONE position
 __global__ void __launch_bounds__(256) conv_dot_kernel(const DotArgs d) {
   const IgemmArgs& a = d.a;
   const PhaseGeom& P = a.G.ph[blockIdx.y];
-  const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool share = d.per_block == 1;      // few positions with a very long K (UCF video-D last layer: 16 x 32768)
+  const int m = share ? blockIdx.x : blockIdx.x * 4 + wave;
+  __shared__ float part[4][4];
   if (m >= P.M) return;
   const int Cg = a.G.Cg, Ncols = a.G.Ncols;
   const int qw = m % P.Mw; int t = m / P.Mw;
@@ -657,7 +659,7 @@ __global__ void __launch_bounds__(256) conv_dot_kernel(const DotArgs d) {
   const bool xf = a.scale != nullptr;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   const float* wp = a.w + P.w_off;
-  for (int k = lane * 4; k < P.K; k += 256) {
+  for (int k = lane * 4 + (share ? wave * 256 : 0); k < P.K; k += (share ? 1024 : 256)) {
     const int tap = (int)fdiv((uint32_t)k, d.dCg), c = k - tap * Cg;
     const int jw = tap % P.Tw, t2 = tap / P.Tw, jh = t2 % P.Th, jd = t2 / P.Th;
     const int id = bd + a.G.J * jd, ih = bh + a.G.J * jh, iw = bw + a.G.J * jw;
@@ -679,7 +681,16 @@ __global__ void __launch_bounds__(256) conv_dot_kernel(const DotArgs d) {
     float s = acc[n];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) a.out[oo + n] = a.epilogue == GODE_EPI_TANH ? tanhf(s) : s;
+    if (!share) {
+      if (lane == 0) a.out[oo + n] = a.epilogue == GODE_EPI_TANH ? tanhf(s) : s;
+    } else if (lane == 0) part[wave][n] = s;
+  }
+  if (share) {               // (all four waves of the workgroup work on the same m, so none has returned early)
+    __syncthreads();
+    if (threadIdx.x < Ncols) {
+      const float s = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+      a.out[oo + threadIdx.x] = a.epilogue == GODE_EPI_TANH ? tanhf(s) : s;
+    }
   }
 }
 
@@ -949,7 +960,8 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
     }
     if (vec && kp_ok && G.Ncols <= 4 && op->stats == nullptr && maxM <= 16384 && minK >= 512 && op->tile == 0) {
       DotArgs D; D.a = A; D.dCg = make_fastdiv((uint32_t)G.Cg);
-      hipLaunchKernelGGL(conv_dot_kernel, dim3(gode_ceil_div(maxM, 4), G.nphase), dim3(256), 0, st, D);
+      D.per_block = (maxM <= 256 && minK >= 4096) ? 1 : 4;
+      hipLaunchKernelGGL(conv_dot_kernel, dim3(D.per_block == 1 ? maxM : gode_ceil_div(maxM, 4), G.nphase), dim3(256), 0, st, D);
       GODE_LAUNCH_CHECK();
       return 0;
     }
