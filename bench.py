@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--ode-step-size", type=float, default=None,
                     help="torchdiffeq options={'step_size': h} for the rk4 solve (0.05 = the \"RK4 20 steps\" of "
                          "BASELINE configs[1]); default: the reference's own call, 15 steps on the output times")
+    ap.add_argument("--ode-method", default="rk4", choices=["rk4", "dopri5"],
+                    help="rk4 = the reference's call; dopri5 = torchdiffeq's adaptive default (BASELINE configs[3] wording)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -167,6 +169,8 @@ def main():
     gen.cuda(); dv.cuda(); di.cuda()
     if a.ode_step_size is not None:
         gen.ode_step_size = a.ode_step_size
+    if a.ode_method != "rk4" and a.config != "odernn":
+        gen.ode_method = a.ode_method
     if distributed:   # replicas start from rank 0's weights
         for m in (gen, dv, di):
             for t in list(m.parameters()) + list(m.buffers()):
@@ -205,6 +209,8 @@ def main():
                            "rk4 as the reference code does, dim_hidden=16",
                     "odernn": "Rotated-MNIST MoCoGAN+ODE-RNN, gen.sample_videos(32): batch 32/GPU, dopri5 (1e-7/1e-9) "
                               "+ GRUCell per frame"}[a.config]
+        if a.ode_method != "rk4" and a.config != "odernn":
+            workload += f"; ODE solved with {a.ode_method} (rtol 1e-7, atol 1e-9) instead of the reference's rk4 call"
         if a.ode_step_size is not None:
             workload += (f"; rk4 options step_size={a.ode_step_size} (solver grid of "
                          f"{int(np.ceil(1 / a.ode_step_size))} steps, outputs interpolated as torchdiffeq does)")

@@ -62,7 +62,8 @@ class OdeParams(C.Structure):
 class OdeFwdOp(C.Structure):
     _fields_ = [("p", OdeParams), ("x", ptr), ("content", ptr), ("dt", ptr), ("sel_t", ptr), ("z", ptr),
                 ("traj", ptr), ("N", i32), ("T", i32), ("substeps", i32), ("prenet", i32), ("zcols", i32), ("G", i32),
-                ("grid_dt", ptr), ("emit_at", ptr), ("emit_w", ptr)]
+                ("grid_dt", ptr), ("emit_at", ptr), ("emit_w", ptr), ("method", i32), ("pad2_", i32), ("rtol", f32),
+                ("atol", f32), ("tout", ptr), ("nsteps", ptr)]
     KIND = OP_ODE_FWD
 
 

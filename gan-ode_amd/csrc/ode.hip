@@ -103,7 +103,17 @@ __global__ void __launch_bounds__(64) ode_fwd_kernel(const gode_ode_fwd_op a) {
 
 }
 
+int gode_launch_ode_dopri5(const gode_ode_fwd_op* op, hipStream_t st);   // odernn.hip
+
 extern "C" int gode_ode_fwd(const gode_ode_fwd_op* op, void* stream) {
+  if (op && op->method == 1) {
+    if (!op->x || !op->z || !op->tout || op->N <= 0 || op->T < 1 || !(op->rtol > 0.f) || !(op->atol >= 0.f)) return GODE_E_ARG;
+    if (op->zcols < 68 || op->zcols % 4 != 0) return GODE_E_ARG;
+    if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2) return GODE_E_ARG;
+    if (op->prenet && (!op->p.Wa || !op->p.ba || !op->p.Wb || !op->p.bb)) return GODE_E_ARG;
+    return gode_launch_ode_dopri5(op, (hipStream_t)stream);
+  }
+  if (op && op->method != 0) return GODE_E_ARG;
   if (!op || !op->x || !op->z || !op->dt || op->N <= 0 || op->T < 1 || op->substeps < 1) return GODE_E_ARG;
   if (op->grid_dt && (!op->emit_at || !op->emit_w || op->G < 1)) return GODE_E_ARG;
   if (op->zcols < 68 || op->zcols % 4 != 0) return GODE_E_ARG;

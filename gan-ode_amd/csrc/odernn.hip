@@ -154,6 +154,122 @@ __global__ void __launch_bounds__(256) latent_content_kernel(const float* conten
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Plain Neural-ODE latent with torchdiffeq's dopri5 (gode_ode_fwd_op.method == 1): pre-net, then ONE adaptive solve over
+// the T output times; every output is read off the 4th-order interpolant of the last accepted step, exactly the
+// RKAdaptiveStepsizeODESolver flow (advance while target > t1, then evaluate).  Step control, error norm and clock as in
+// odernn_fwd_kernel.  The interpolation abscissa is formed from the fp32-rounded times as torchdiffeq does.
+__global__ void __launch_bounds__(RNN_BLOCK_SAMPLES * 4) ode_dopri5_fwd_kernel(const gode_ode_fwd_op a) {
+  __shared__ float red[RNN_BLOCK_SAMPLES / 16];
+  const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int s = l & 15, g = l >> 4;
+  const int n = blockIdx.x * RNN_BLOCK_SAMPLES + wv * 16 + s;
+  const bool valid = n < a.N;
+  const int T = a.T;
+  const int nblk = (a.N - blockIdx.x * RNN_BLOCK_SAMPLES) < RNN_BLOCK_SAMPLES ? (a.N - blockIdx.x * RNN_BLOCK_SAMPLES) : RNN_BLOCK_SAMPLES;
+  const float inv_count = 1.f / (float)(nblk * 16);
+  // tolerances pinned to vector registers: with both in SGPRs hipcc (ROCm 7.2) emits a packed-fp32 VOP3P with two scalar
+  // sources for `atol + rtol * max(...)` and the assembler rejects it ("violates constant bus restriction")
+  float rtol = a.rtol, atol = a.atol;
+  asm volatile("" : "+v"(rtol), "+v"(atol));
+
+  f32x4 y0 = valid ? ld4(a.x + n * 16 + 4 * g) : zero4();
+  if (a.prenet) {
+    f32x4 acc = ld4(a.p.bb + 4 * g);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      f32x4 hh = matvec(ld4(a.p.Wa + (16 * m + s) * 16 + 4 * g), y0, ld4(a.p.ba + 16 * m + 4 * g));
+      acc = matvec(ld4(a.p.Wb + s * 64 + 16 * m + 4 * g), lrelu4(hh), acc);
+    }
+    y0 = lrelu4(acc);
+  }
+  const f32x4 w1 = ld4(a.p.W1 + s * 16 + 4 * g), w2 = ld4(a.p.W2 + s * 16 + 4 * g);
+  const f32x4 b1 = ld4(a.p.b1 + 4 * g), b2 = ld4(a.p.b2 + 4 * g);
+  auto f = [&](const f32x4 yy) { return matvec(w2, tanh4(matvec(w1, yy, b1)), b2); };
+  auto rms = [&](const f32x4 v) { return sqrtf(block_sum(valid ? sq4(v) : 0.f, red, nw) * inv_count); };
+  const int tsel = (a.sel_t && valid) ? a.sel_t[n] : -1;
+  auto emit = [&](int t, const f32x4 v) {
+    if (!valid) return;
+    if (a.traj) *reinterpret_cast<f32x4*>(a.traj + ((int64_t)n * T + t) * 16 + 4 * g) = v;
+    if (a.sel_t == nullptr) *reinterpret_cast<f32x4*>(a.z + ((int64_t)n * T + t) * a.zcols + 4 * g) = v;
+    else if (t == tsel) *reinterpret_cast<f32x4*>(a.z + (int64_t)n * a.zcols + 4 * g) = v;
+  };
+  emit(0, y0);
+
+  f32x4 f0 = f(y0);
+  double dtd;
+  {
+    const f32x4 sc = atol + abs4(y0) * rtol;
+    const float d0 = rms(y0 / sc), d1 = rms(f0 / sc);
+    const float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
+    const f32x4 f1 = f(y0 + h0 * f0);
+    const float d2 = rms((f1 - f0) / sc) / h0;
+    const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
+    dtd = (double)fminf(100.f * h0, h1);
+  }
+  double tcur = (double)a.tout[0], seg0 = tcur, seg1 = tcur;
+  f32x4 ca = y0, cb = y0, cc = y0, cd = y0, ce = y0;     // interp = (y, y, y, y, y) before the first accepted step
+  int steps = 0;
+  for (int j = 1; j < T; ++j) {
+    const double target = (double)a.tout[j];
+    while (target > seg1 && steps < 1000000) {
+      const float dt = (float)dtd;
+      const f32x4 k1 = f0;
+      const f32x4 k2 = f(y0 + dt * (0.2f * k1));
+      const f32x4 k3 = f(y0 + dt * ((3.f / 40.f) * k1 + (9.f / 40.f) * k2));
+      const f32x4 k4 = f(y0 + dt * ((44.f / 45.f) * k1 + (-56.f / 15.f) * k2 + (32.f / 9.f) * k3));
+      const f32x4 k5 = f(y0 + dt * ((19372.f / 6561.f) * k1 + (-25360.f / 2187.f) * k2 + (64448.f / 6561.f) * k3 +
+                                    (-212.f / 729.f) * k4));
+      const f32x4 k6 = f(y0 + dt * ((9017.f / 3168.f) * k1 + (-355.f / 33.f) * k2 + (46732.f / 5247.f) * k3 +
+                                    (49.f / 176.f) * k4 + (-5103.f / 18656.f) * k5));
+      const f32x4 y1 = y0 + dt * ((35.f / 384.f) * k1 + (500.f / 1113.f) * k3 + (125.f / 192.f) * k4 +
+                                  (-2187.f / 6784.f) * k5 + (11.f / 84.f) * k6);
+      const f32x4 k7 = f(y1);
+      const f32x4 err = dt * ((35.f / 384.f - 1951.f / 21600.f) * k1 + (500.f / 1113.f - 22642.f / 50085.f) * k3 +
+                              (125.f / 192.f - 451.f / 720.f) * k4 + (-2187.f / 6784.f + 12231.f / 42400.f) * k5 +
+                              (11.f / 84.f - 649.f / 6300.f) * k6 + (-1.f / 60.f) * k7);
+      const f32x4 tol = atol + rtol * max4(abs4(y0), abs4(y1));
+      const float ratio = rms(err / tol);
+      if (ratio <= 1.f) {
+        const f32x4 ymid = y0 + dt * ((6025192743.f / 30085553152.f / 2.f) * k1 + (51252292925.f / 65400821598.f / 2.f) * k3 +
+                                      (-2691868925.f / 45128329728.f / 2.f) * k4 + (187940372067.f / 1594534317056.f / 2.f) * k5 +
+                                      (-1776094331.f / 19743644256.f / 2.f) * k6 + (11237099.f / 235043384.f / 2.f) * k7);
+        ca = 2.f * dt * (k7 - k1) - 8.f * (y1 + y0) + 16.f * ymid;
+        cb = dt * (5.f * k1 - 3.f * k7) + 18.f * y0 + 14.f * y1 - 32.f * ymid;
+        cc = dt * (k7 - 4.f * k1) - 11.f * y0 - 5.f * y1 + 16.f * ymid;
+        cd = dt * k1;
+        ce = y0;
+        seg0 = tcur; seg1 = tcur + dtd;
+        tcur = seg1; y0 = y1; f0 = k7;
+      }
+      float fac;
+      if (ratio == 0.f) fac = 10.f;
+      else { fac = 0.9f * powf(ratio, -0.2f); fac = fminf(10.f, fmaxf(fac, ratio < 1.f ? 1.f : 0.2f)); }
+      dtd *= (double)fac;
+      ++steps;
+    }
+    const float x = ((float)target - (float)seg0) / ((float)seg1 - (float)seg0);
+    emit(j, ce + x * (cd + x * (cc + x * (cb + x * ca))));
+  }
+  if (a.nsteps && threadIdx.x == 0) a.nsteps[blockIdx.x] = steps;
+}
+
+int gode_launch_ode_dopri5(const gode_ode_fwd_op* op, hipStream_t st) {
+  if (op->content) {
+    const int rows_per = op->sel_t ? 1 : op->T;
+    int64_t total4 = (int64_t)op->N * rows_per * ((op->zcols - 16) >> 2);
+    int blocks = (int)((total4 + 255) / 256); if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(latent_content_kernel, dim3(blocks), dim3(256), 0, st, op->content, op->z, op->N, rows_per, op->zcols);
+    GODE_LAUNCH_CHECK();
+  }
+  const int nblocks = (op->N + RNN_BLOCK_SAMPLES - 1) / RNN_BLOCK_SAMPLES;
+  const int per = op->N < RNN_BLOCK_SAMPLES ? op->N : RNN_BLOCK_SAMPLES;
+  const int threads = ((per + 15) / 16) * 64;
+  hipLaunchKernelGGL(ode_dopri5_fwd_kernel, dim3(nblocks), dim3(threads), 0, st, *op);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int gode_odernn_fwd(const gode_odernn_fwd_op* op, void* stream) {
   if (!op || !op->noise || !op->z || op->N <= 0 || op->T < 1 || !(op->rtol > 0.f) || !(op->atol >= 0.f)) return GODE_E_ARG;
   if (op->zcols < 68 || op->zcols % 4 != 0) return GODE_E_ARG;

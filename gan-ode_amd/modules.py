@@ -148,7 +148,8 @@ class _GenPlan:
 
     def _programs(self):
         ps = self._ode_params()
-        ptrs = tuple(dptr(p) for p in ps) + (self.gen.ode_step_size,)
+        ptrs = tuple(dptr(p) for p in ps) + (self.gen.ode_step_size, self.gen.ode_method, self.gen.ode_rtol,
+                                             self.gen.ode_atol)
         if ptrs != self._ode_ptrs:
             self._ode_ptrs = ptrs
             op = L.OdeParams(*ptrs[:8])
@@ -160,13 +161,26 @@ class _GenPlan:
                                      sel_t=dptr(self.sel), gz=None, work=dptr(self.ode_work), grads=None, N=self.n,
                                      T=self.T, substeps=self.gen.ode_substeps, prenet=prenet, accumulate=0, zcols=Z_COLS)
             self._grid = None
-            if self.gen.ode_step_size is not None and self.T > 1:
+            if self.gen.ode_method == "dopri5":
+                # torchdiffeq's adaptive solver over the output times; the adjoint is the same continuous adjoint,
+                # integrated here with `adjoint_substeps` fixed Kutta-3/8 steps per output interval (torchdiffeq
+                # integrates it adaptively to rtol/atol): the deviation recorded for the ODE-RNN generator
+                self._tout = torch.linspace(0, 1, self.T).float().to(self.device)
+                self._nsteps = torch.zeros((self.n + 63) // 64, dtype=torch.int32, device=self.device)
+                self.fwd_op.method, self.fwd_op.rtol, self.fwd_op.atol = 1, float(self.gen.ode_rtol), float(self.gen.ode_atol)
+                self.fwd_op.tout, self.fwd_op.nsteps = dptr(self._tout), dptr(self._nsteps)
+            elif self.gen.ode_method != "rk4":
+                raise NotImplementedError(f"ode_method {self.gen.ode_method!r}: libgode implements 'rk4' (the reference's "
+                                          "call) and 'dopri5'")
+            elif self.gen.ode_step_size is not None and self.T > 1:
                 gd = self._grid = self._solver_grid(float(self.gen.ode_step_size))
                 self.fwd_op.G = gd["G"]
                 self.fwd_op.grid_dt, self.fwd_op.emit_at, self.fwd_op.emit_w = dptr(gd["grid_dt"]), dptr(gd["emit_at"]), dptr(gd["emit_w"])
                 self.bwd_op.bstep_off, self.bwd_op.bstep_dt = dptr(gd["bstep_off"]), dptr(gd["bstep_dt"])
             self.fwd_prog = L.Program([self.fwd_op])
         self.fwd_op.substeps = self.bwd_op.substeps = self.gen.ode_substeps
+        if self.gen.ode_method == "dopri5":
+            self.bwd_op.substeps = self.gen.adjoint_substeps
 
     def forward(self, x_host, content_host, sel_host, training, keep):
         self._programs()
@@ -257,6 +271,9 @@ class VideoGenerator(nn.Module):
 
     mnist = False
     _plan_cls = None   # set below (_GenPlan)
+    # the reference passes method='rk4' (models/mocogan_ode.py:50,144); 'dopri5' is what BASELINE configs[3] words
+    ode_method = "rk4"
+    ode_rtol, ode_atol, adjoint_substeps = 1e-7, 1e-9, 4
 
     def __init__(self, n_channels, dim_z_content, dim_z_category, dim_z_motion, video_length, ode_fn=ODEFunc,
                  dim_hidden=None, linear=True, ngf=64):

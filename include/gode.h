@@ -151,6 +151,11 @@ typedef struct gode_ode_fwd_op {
    * step emit_at[j] as y0 + emit_w[j]*(y1 - y0) (emit_w == 1: y1 itself).  grid_dt == NULL: the grid is the output
    * times (dt[T-1], `substeps` equal sub-steps each) -- the reference's own call. */
   const float* grid_dt; const int32_t* emit_at; const float* emit_w;
+  /* method 1: torchdiffeq's dopri5 (adaptive Dormand-Prince 5(4), controller and 4th-order dense output as in
+   * gode_odernn_fwd) over the T output times tout[T] (increasing, tout[0] = start); the error norm is taken jointly
+   * over the trajectories of a workgroup (<= 64; torchdiffeq: over the whole batch).  nsteps[ceil(N/64)] (nullable)
+   * receives the number of trial steps.  method 0: fixed-grid rk4 (above). */
+  int32_t method, pad2_; float rtol, atol; const float* tout; int32_t* nsteps;
 } gode_ode_fwd_op;
 int gode_ode_fwd(const gode_ode_fwd_op* op, void* stream);
 /* adjoint backward (torchdiffeq odeint_adjoint semantics: per output interval ONE reverse-time RK4(3/8) step of
