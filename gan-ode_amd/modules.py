@@ -72,6 +72,44 @@ class ODEFunc(nn.Module):
         raise RuntimeError("ODEFunc is evaluated inside libgode's fused RK4 kernels (gode_ode_fwd/bwd)")
 
 
+def solver_grid_arrays(T, step_size):
+    """torchdiffeq options={'step_size': h} (FixedGridODESolver) for t = linspace(0, 1, T): the solver walks its own
+    grid arange(niters)*h + t0 (last point clamped to t_end) and interpolates the requested outputs linearly; the
+    adjoint pass solves every output interval on the grid built the same way for the reversed span.  All arithmetic
+    is fp32 torch on the host, operation for operation what torchdiffeq executes, so the device gets bit-identical
+    step sizes and interpolation weights.  Returns CPU tensors: grid_dt[G], emit_at[T] (grid step after which output
+    j is produced), emit_w[T] (interpolation weight; 0 / 1 = an end point itself), bstep_off[T], bstep_dt[...]."""
+    t = torch.linspace(0, 1, T).float()
+
+    def grid_of(tt):
+        start, end = tt[0], tt[-1]
+        niters = int(torch.ceil((end - start) / step_size + 1).item())
+        gr = torch.arange(0, niters, dtype=tt.dtype) * step_size + start
+        gr[-1] = end
+        return gr
+
+    gr = grid_of(t)
+    gdt = gr[1:] - gr[:-1]
+    emit_at = torch.full((T,), -1, dtype=torch.int32)
+    emit_w = torch.zeros(T, dtype=torch.float32)
+    j = 1
+    for i in range(len(gr) - 1):
+        a, b = gr[i], gr[i + 1]
+        while j < T and bool(b >= t[j]):
+            emit_at[j] = i
+            emit_w[j] = 0.0 if bool(t[j] == a) else (1.0 if bool(t[j] == b) else (t[j] - a) / (b - a))
+            j += 1
+    assert j == T
+    off, steps = [0], []
+    for i in range(1, T):                      # adjoint of output interval i -> i-1: reversed span, t -> -t
+        rg = grid_of(-t[i - 1:i + 1].flip(0))
+        d = rg[1:] - rg[:-1]
+        steps.append(d)
+        off.append(off[-1] + len(d))
+    return dict(G=len(gdt), grid_dt=gdt, emit_at=emit_at, emit_w=emit_w,
+                bstep_off=torch.tensor(off, dtype=torch.int32), bstep_dt=torch.cat(steps))
+
+
 class _GenPlan:
     """ODE solve + decoder for `n_traj` trajectories.  full: rows = n_traj*T; select: rows = n_traj (one chosen
     time per trajectory, sample_images)."""
@@ -109,42 +147,8 @@ class _GenPlan:
         return pre + (f[0].weight, f[0].bias, f[2].weight, f[2].bias)
 
     def _solver_grid(self, step_size):
-        """torchdiffeq options={'step_size': h} (FixedGridODESolver): the solver walks its own grid
-        arange(niters)*h + t0 (last point clamped to t_end) and interpolates the requested outputs linearly; the
-        adjoint pass solves every output interval on the grid built the same way for the reversed span.  All
-        arithmetic below is fp32 torch on the host, operation for operation what torchdiffeq executes, so the
-        device gets bit-identical step sizes and interpolation weights."""
-        T = self.T
-        t = torch.linspace(0, 1, T).float()
-
-        def grid_of(tt):
-            start, end = tt[0], tt[-1]
-            niters = int(torch.ceil((end - start) / step_size + 1).item())
-            gr = torch.arange(0, niters, dtype=tt.dtype) * step_size + start
-            gr[-1] = end
-            return gr
-
-        gr = grid_of(t)
-        gdt = gr[1:] - gr[:-1]
-        emit_at = torch.full((T,), -1, dtype=torch.int32)
-        emit_w = torch.zeros(T, dtype=torch.float32)
-        j = 1
-        for i in range(len(gr) - 1):
-            a, b = gr[i], gr[i + 1]
-            while j < T and bool(b >= t[j]):
-                emit_at[j] = i
-                emit_w[j] = 0.0 if bool(t[j] == a) else (1.0 if bool(t[j] == b) else (t[j] - a) / (b - a))
-                j += 1
-        assert j == T
-        off, steps = [0], []
-        for i in range(1, T):                      # adjoint of output interval i -> i-1: reversed span, t -> -t
-            rg = grid_of(-t[i - 1:i + 1].flip(0))
-            d = rg[1:] - rg[:-1]
-            steps.append(d)
-            off.append(off[-1] + len(d))
-        dev = self.device
-        return dict(G=len(gdt), grid_dt=gdt.to(dev), emit_at=emit_at.to(dev), emit_w=emit_w.to(dev),
-                    bstep_off=torch.tensor(off, dtype=torch.int32).to(dev), bstep_dt=torch.cat(steps).to(dev))
+        gd = solver_grid_arrays(self.T, step_size)
+        return {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in gd.items()}
 
     def _programs(self):
         ps = self._ode_params()

@@ -191,3 +191,39 @@ def test_odernn_dropin_constructs_and_draws_like_the_oracle():
     assert torch.equal(oc[::16], content)
     with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
         gen.sample_videos(2)
+
+
+def test_solver_grid_arrays_reproduce_the_fixed_grid_solver():
+    """Host logic of the `ode_step_size` option (= torchdiffeq options={'step_size': h}): the step sizes, output
+    slots and interpolation weights handed to the device kernel, replayed on the CPU with the oracle's Kutta-3/8
+    increment, must give exactly what oracle/ode_ref.py:fixed_grid_solve (the restated FixedGridODESolver) returns --
+    forward on the solver grid and per-interval reversed grids for the adjoint pass."""
+    from gan_ode_amd.modules import solver_grid_arrays
+    from oracle import ode_ref
+    torch.manual_seed(3)
+    W1, W2 = torch.randn(16, 16) * 0.4, torch.randn(16, 16) * 0.4
+    f = lambda t, y: torch.tanh(y @ W1.T) @ W2.T          # noqa: E731  (autonomous, like ODEFunc)
+    y0 = torch.randn(5, 16)
+    T = 16
+    t = torch.linspace(0, 1, T).float()
+    for h in (0.05, 0.04, 1.0 / 15.0, 0.2):
+        gd = solver_grid_arrays(T, h)
+        want = ode_ref.fixed_grid_solve(f, y0, t, "rk4", step_size=h)
+        got = [y0]
+        y, j = y0, 1
+        for i in range(gd["G"]):
+            dt = gd["grid_dt"][i]
+            y1 = y + ode_ref.kutta38_increment(f, torch.zeros(()), dt, dt, y)
+            while j < T and int(gd["emit_at"][j]) == i:
+                w = gd["emit_w"][j]
+                got.append(y1 if float(w) == 1.0 else (y if float(w) == 0.0 else y + w * (y1 - y)))
+                j += 1
+            y = y1
+        assert j == T and torch.equal(torch.stack(got), want), h
+        # reversed-span grids of the adjoint pass: same constructor on (-t_i, -t_{i-1})
+        for i in range(1, T):
+            seg = -t[i - 1:i + 1].flip(0)
+            rg = ode_ref._grid_from_step_size(seg, h)
+            d = rg[1:] - rg[:-1]
+            lo, hi = int(gd["bstep_off"][i - 1]), int(gd["bstep_off"][i])
+            assert torch.equal(gd["bstep_dt"][lo:hi], d), (h, i)
