@@ -188,6 +188,21 @@ def main():
     dt = _timed(sample, a.steps, a.warmup, distributed, after_warmup=G.freeze_host_gc)
     vps = world * B * a.steps / dt
 
+    # per-step spread (rank 0): GPU time between stream markers recorded after every step of a second, untimed-by-the-
+    # contract pass of min(steps, 200) steps -- reported beside the headline, never used for `value`
+    spread = None
+    if rank == 0:
+        k = min(a.steps, 200)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+        marks[0].record()
+        for i in range(k):
+            sample()
+            marks[i + 1].record()
+        torch.cuda.synchronize()
+        per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(k))
+        spread = {"p10": round(per[int(0.1 * (k - 1))], 4), "p50": round(per[(k - 1) // 2], 4),
+                  "p90": round(per[int(0.9 * (k - 1))], 4), "steps": k}
+
     # G / D step and whole-iteration milliseconds (synthetic real data resident on the GPU)
     tr = G.GanTrainer(gen, dv, di)
     g = torch.Generator().manual_seed(99 + rank)
@@ -219,6 +234,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}"},
+            "step_ms_spread": spread,
             "d_step_ms": round(d_ms, 3), "g_step_ms": round(g_ms, 3), "iteration_ms": round(it_ms, 3),
             "train_videos_per_s": round(world * B / (it_ms / 1e3), 2),
             "roofline": roof, "cpu_baseline": cpu,
