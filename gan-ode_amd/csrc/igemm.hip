@@ -5,10 +5,12 @@
 // the generator's first layer (FULLK).  Reference layers: models/mocogan.py:72-89,138-159,200-215,
 // models/mocogan_ode.py:66-84.
 //
-// Data flow per workgroup (256 threads = 4 waves, BMxBN output tile, K slabs of 32):
-//   global (channels-last, 128-B rows)  --float4 gathers + fused BN/activation of the previous layer-->  registers
-//   --ds_write_b128-->  LDS [row][36] (pad 4 => conflict-free ds_read_b128)  --> 32x32x2 MFMA, 2x2 tiles / wave
-//   slab s+1 is fetched into registers while slab s is multiplied (two LDS buffers, one barrier per slab).
+// Data flow per workgroup (256 threads = 4 waves, BMxBN output tile, K slabs of 32), three staging paths:
+//   LDS-DMA (igemm_fast_kernel MODE 2; every heavy, transform-free GEMM): global --global_load_lds_dwordx4--> LDS
+//     [row][32], 16-byte chunks XOR-swizzled through the source address, two buffers, one barrier per slab;
+//   registers (MODE 0/1 and the generic igemm_kernel; BN/activation of the previous layer fused into the load, odd
+//     channel counts, strided sources): float4 (or scalar) gathers -> registers -> ds_write_b128 -> LDS [row][36];
+//   then ds_read_b128 fragments -> 32x32x2 MFMA, 2x2 (2x1, 1x1) tiles per wave.
 // MFMA k-index trick: lane half h supplies k = 4h+j in step j, so one ds_read_b128 feeds four MFMAs.
 // Epilogue: raw (or tanh) store, 128-B coalesced along channels, plus deterministic per-column partial sums for
 // train-mode BatchNorm (no atomics).
@@ -270,9 +272,9 @@ __device__ __attribute__((aligned(16))) const float gode_zero16[4] = {0.f, 0.f, 
 // a tap and the tap decode is wave-uniform scalar work), K % 32 == 0.  The loop body is one basic block: loads are
 // unconditional (clamped address + mask), the BN/activation transform is branch-free, and the staging work of slab
 // s+1 is placed between the MFMA groups of slab s so that it issues in the shadow of the matrix pipe.
-// DB=true : two LDS buffers, one barrier per slab, staging interleaved with this wave's own MFMAs.
-// DB=false: one LDS buffer (half the LDS => twice the resident workgroups, 4 waves per SIMD), two barriers per slab;
-//           the staging of one workgroup is covered by the MFMAs of the three others on the SIMD.
+// MODE 1 : registers, two LDS buffers, one barrier per slab, staging interleaved with this wave's own MFMAs.
+// MODE 0 : registers, one LDS buffer (half the LDS => twice the resident workgroups), two barriers per slab; the
+//           staging of one workgroup is covered by the MFMAs of the others on the SIMD.  Default when XF.
 // MODE 2 (LDS-DMA): the slab is written to LDS by `global_load_lds_dwordx4` (no VGPR round trip, no ds_write pass);
 //           two unpadded LDS buffers whose 16-byte chunks are XOR-swizzled through the SOURCE address (the DMA
 //           destination is lane-linear), one barrier per slab.  Transform-free instantiation only.
