@@ -2,8 +2,10 @@
 //
 //   dW[co][tap][ci] = sum over y positions m of  Y[m][co] * X[pos(m,tap)][ci]
 // (Y = y-side tensor, dense [M][Co]; X = x-side tensor gathered at the tap offset, zero outside).  The reduction
-// index m is the MFMA k index, so both LDS tiles keep the memory order [position][channel] and are read with
-// ds_read_b32 (consecutive lanes -> consecutive channels, conflict free); no transpose is ever materialised.
+// index m is the MFMA k index, so both LDS tiles keep the memory order [position][channel] and are read along the
+// channel axis (consecutive lanes -> consecutive channels, conflict free; the FAST kernel reads one ds_read_b64 per
+// operand and k by giving MFMA row r of sub-tile i the channel 2r+i); no transpose is ever materialised.  Transform-free
+// operands (the heavy layers) are staged global -> LDS by global_load_lds_dwordx4 into two buffers.
 // The reduction is cut into `splits` slabs (grid.z), each writing its own [Co][taps*Ci] partial; a second kernel
 // sums the partials in fixed order and scatters into PyTorch's canonical W[co][ci][taps] layout (deterministic,
 // no float atomics).  The BN+activation of the producing layer is fused into whichever operand is an activation.
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgradArgs a) {
 }
 
 // FAST path (vector loads on both operands): branch-free loop body (clamped loads + masks, magic-number position
-// decode), ONE LDS buffer (32 KB at 128x128 => four workgroups per CU cover each other's staging).
+// decode).  GL=false: register staging into ONE LDS buffer (32 KB at 128x128), BN/activation fused into the load.
 __device__ __attribute__((aligned(16))) const float gode_wg_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 // GL: transform-free operands go global -> LDS by `global_load_lds_dwordx4` (the [position][channel] image is already
