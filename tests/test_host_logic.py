@@ -128,6 +128,23 @@ def _bucket_worker(rank, world, port, q):
     for i, p in enumerate(params[:4]):
         ok = ok and torch.equal(views[p], torch.full_like(p, 3.0 * (i + 1)))     # (1 + 2) * (i + 1)
         ok = ok and views[p].data_ptr() >= flat.data_ptr()                        # views alias the bucket (no copy back)
+    # the GradArena form of the same step (what the GPU trainer uses): writers store / add into the arena, p.grad is a
+    # view of it, ONE all-reduce over the whole flat buffer, parameters nobody wrote keep grad None
+    arena = G.train.GradArena(params)
+    arena.begin()
+    ok = ok and all(p.grad is None for p in params)
+    for i, p in enumerate(params[:4]):
+        v, acc = arena.target(p)
+        ok = ok and not acc
+        v.fill_(float(rank + 1) * (i + 1))                   # first pass of the step stores ...
+        v2, acc2 = arena.target(p)
+        ok = ok and acc2 and v2.data_ptr() == v.data_ptr()
+        v2.add_(1.0)                                         # ... the second pass adds in place
+    arena.end()
+    dist.all_reduce(arena.flat)
+    for i, p in enumerate(params[:4]):
+        ok = ok and torch.equal(p.grad, torch.full_like(p, 3.0 * (i + 1) + 2.0)) and p.grad.data_ptr() == arena.views[p].data_ptr()
+    ok = ok and all(p.grad is None for p in params[4:])
     q.put((rank, ok))
     dist.destroy_process_group()
 
