@@ -17,33 +17,34 @@
 #include "ode_common.h"
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) ode_fwd_kernel(const gode_ode_fwd_op a) {
-  const int l = threadIdx.x, s = l & 15, g = l >> 4;
-  const int n0 = blockIdx.x * 16, n = n0 + s;
-  const bool valid = n < a.N;
+// Launched with 256 threads when there is a content code to broadcast: wave 0 runs the (strictly serial) solve of the
+// 16 trajectories, waves 1-3 write the content columns of the same latent rows at the same time on the other SIMDs
+// (the broadcast used to run ahead of the solve on the one wave: 31 us per launch at N = 32, 21 us for the solve alone).
+__global__ void __launch_bounds__(256) ode_fwd_kernel(const gode_ode_fwd_op a) {
+  const int n0 = blockIdx.x * 16;
   const int T = a.T;
-
-  // content columns 16..65 (the same 50 values on all T rows of a trajectory) and zero pad 66..71: staged once in LDS,
-  // written as 14 aligned float4 per latent row; issued first so the stores drain while the solve runs
-  if (a.content) {
-    __shared__ __attribute__((aligned(16))) float cbuf[16][52];
-    for (int i = l; i < 16 * 52; i += 64) {
-      const int ns = i / 52, cc = i - ns * 52;
-      cbuf[ns][cc] = (cc < 50 && n0 + ns < a.N) ? a.content[(int64_t)(n0 + ns) * 50 + cc] : 0.f;
-    }
-    __syncthreads();
+  if (threadIdx.x >= 64) {
+    // content columns 16..65 (the same 50 values on all T rows of a trajectory) + zero pad, one float4 per thread and
+    // turn; rows are 200 B in `content`, so the four values are gathered one by one (L1-resident: 3.2 KB per workgroup)
     const int rows_per = a.sel_t ? 1 : T;
     const int q4 = (a.zcols - 16) >> 2;      // float4 chunks of content + pad per latent row
     const int total4 = 16 * rows_per * q4;
-    for (int i = l; i < total4; i += 64) {
+    for (int i = threadIdx.x - 64; i < total4; i += 192) {
       const int rr = i / q4, q = i - rr * q4;
       const int ns = rr / rows_per, tt = rr - ns * rows_per;
       if (n0 + ns < a.N) {
-        const f32x4 v = q < 13 ? *reinterpret_cast<const f32x4*>(&cbuf[ns][4 * q]) : zero4();
+        const float* c = a.content + (int64_t)(n0 + ns) * 50 + 4 * q;
+        f32x4 v = zero4();
+        if (q < 12) v = f32x4{c[0], c[1], c[2], c[3]};
+        else if (q == 12) v = f32x4{c[0], c[1], 0.f, 0.f};
         *reinterpret_cast<f32x4*>(a.z + ((int64_t)(n0 + ns) * rows_per + tt) * a.zcols + 16 + 4 * q) = v;
       }
     }
+    return;
   }
+  const int l = threadIdx.x, s = l & 15, g = l >> 4;
+  const int n = n0 + s;
+  const bool valid = n < a.N;
 
   f32x4 y = valid ? ld4(a.x + n * 16 + 4 * g) : zero4();
   if (a.prenet) {
@@ -119,7 +120,7 @@ extern "C" int gode_ode_fwd(const gode_ode_fwd_op* op, void* stream) {
   if (op->zcols < 68 || op->zcols % 4 != 0) return GODE_E_ARG;
   if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2) return GODE_E_ARG;
   if (op->prenet && (!op->p.Wa || !op->p.ba || !op->p.Wb || !op->p.bb)) return GODE_E_ARG;
-  hipLaunchKernelGGL(ode_fwd_kernel, dim3((op->N + 15) / 16), dim3(64), 0, (hipStream_t)stream, *op);
+  hipLaunchKernelGGL(ode_fwd_kernel, dim3((op->N + 15) / 16), dim3(op->content ? 256 : 64), 0, (hipStream_t)stream, *op);
   GODE_LAUNCH_CHECK();
   return 0;
 }
