@@ -10,14 +10,15 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const gode_bn_finalize
   const int c = blockIdx.x, tid = threadIdx.x;
   __shared__ double red[2][256];
   if (a.training) {
+    // stats[which][column][row] (column = rep*C + c): consecutive threads read consecutive rows of one column
     const int reps = a.ncols / a.C;
-    const int64_t items = (int64_t)a.rows * reps;
     double s1 = 0.0, s2 = 0.0;
+    const int64_t items = (int64_t)a.rows * reps;
     for (int64_t i = tid; i < items; i += 256) {
-      const int64_t row = i / reps; const int rep = (int)(i - row * reps);
-      const float* p = a.stats + row * 2 * a.ncols + rep * a.C + c;
-      s1 += (double)p[0];
-      s2 += (double)p[a.ncols];
+      const int rep = (int)(i / a.rows); const int r = (int)(i - (int64_t)rep * a.rows);
+      const int64_t o = (int64_t)(rep * a.C + c) * a.rows + r;
+      s1 += (double)a.stats[o];
+      s2 += (double)a.stats[(int64_t)a.ncols * a.rows + o];
     }
     red[0][tid] = s1; red[1][tid] = s2;
     __syncthreads();

@@ -33,6 +33,7 @@ struct IgemmArgs {
   int32_t ksplit, slabs_per_split;   // split-K: grid is ksplit copies of the above; partial tiles go to work
   float* work;
   int32_t out_numel;
+  int32_t stats_rows;   // number of partial-statistics rows of the launch (the stats buffer is [2][ncols][stats_rows])
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs in linear id order (id and id+8 share an XCD and its 4 MiB L2);
@@ -257,9 +258,9 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const IgemmArgs a) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int w = 0; w < WM; ++w) { s1 += sred[(w * BN + c) * 2 + 0]; s2 += sred[(w * BN + c) * 2 + 1]; }
-        float* dst = a.stats + (int64_t)(P.row0 + mblk) * 2 * Ncols;
-        dst[col] = s1;
-        dst[Ncols + col] = s2;
+        // [which][column][row]: the finalize kernel then walks contiguous rows per channel
+        a.stats[(int64_t)col * a.stats_rows + P.row0 + mblk] = s1;
+        a.stats[((int64_t)Ncols + col) * a.stats_rows + P.row0 + mblk] = s2;
       }
     }
   }
@@ -566,9 +567,9 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int w = 0; w < WM; ++w) { s1 += sred[(w * BN + c) * 2 + 0]; s2 += sred[(w * BN + c) * 2 + 1]; }
-        float* dst = a.stats + (int64_t)(P.row0 + mblk) * 2 * Ncols;
-        dst[col] = s1;
-        dst[Ncols + col] = s2;
+        // [which][column][row]: the finalize kernel then walks contiguous rows per channel
+        a.stats[(int64_t)col * a.stats_rows + P.row0 + mblk] = s1;
+        a.stats[((int64_t)Ncols + col) * a.stats_rows + P.row0 + mblk] = s2;
       }
     }
   }
@@ -595,8 +596,8 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce_kernel(const float* w
       out[i] = epilogue == GODE_EPI_TANH ? tanhf(v) : v;
     }
     if (stats) {
-      stats[(int64_t)blockIdx.x * 2 * Ncols + col] = s1;
-      stats[(int64_t)blockIdx.x * 2 * Ncols + Ncols + col] = s2;
+      stats[(int64_t)col * gridDim.x + blockIdx.x] = s1;
+      stats[((int64_t)Ncols + col) * gridDim.x + blockIdx.x] = s2;
     }
   }
 }
@@ -631,7 +632,7 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce_vec_kernel(const floa
       float acc = 0.f;
 #pragma unroll
       for (int r = 0; r < SPLITK_ROWS; ++r) acc += red[which][r][c];
-      if (blockIdx.y * 64 + c < Ncols) stats[((int64_t)blockIdx.x * 2 + which) * Ncols + blockIdx.y * 64 + c] = acc;
+      if (blockIdx.y * 64 + c < Ncols) stats[((int64_t)which * Ncols + blockIdx.y * 64 + c) * gridDim.x + blockIdx.x] = acc;
     }
   }
 }
@@ -946,6 +947,7 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
   A.gsN = (int)gs[0]; A.gsD = (int)gs[1]; A.gsH = (int)gs[2]; A.gsW = (int)gs[3]; A.gsC = (int)gs[4];
   A.act = op->act; A.epilogue = op->epilogue;
   A.stagger = 0;
+  A.stats_rows = rows;
   A.work = op->work; A.out_numel = (int32_t)outn; A.ksplit = 1; A.slabs_per_split = 0; A.MB = 0; A.NB = 0; A.xcd_mode = 0;
   if ((op->scale == nullptr) != (op->shift == nullptr)) return GODE_E_ARG;
   const bool vec = gs[4] == 1 && (G.Cg % 4) == 0 && (gs[0] % 4) == 0 && (gs[1] % 4) == 0 && (gs[2] % 4) == 0 &&

@@ -48,7 +48,8 @@ typedef struct gode_conv_geom {
  *   a = act(v*scale[c] + shift[c])   (train-mode BatchNorm + ReLU/LeakyReLU of the PREVIOUS layer; nullable).
  * Zero padding is applied after the transform.  `wpack` comes from gode_pack_weights for the same geom/dir.
  * If stats != NULL, per-column partial sums (sum, sum of squares) of the raw outputs are written to
- * stats[row][2][ncols] (row = m-block, deterministic), feeding gode_bn_finalize. */
+ * stats[2][ncols][rows] (row = m-block, rows = gode_igemm_stats_rows(op); deterministic), feeding
+ * gode_bn_finalize, which reads each channel's rows contiguously. */
 typedef struct gode_igemm_op {
   gode_conv_geom g;
   int32_t dir, act, epilogue, tile; /* tile: 0 auto */

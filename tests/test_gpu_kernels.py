@@ -60,7 +60,7 @@ def igemm(g, direction, src, w, out_dims, scale=None, shift=None, act=L.ACT_NONE
     stats = None
     if want_stats:
         rows = lib.gode_igemm_stats_rows(C.byref(op))
-        stats = torch.full((rows, 2, out_dims[-1] if direction == L.FPROP else out_dims[-1]), float("nan"), device="cuda")
+        stats = torch.full((2, out_dims[-1], rows), float("nan"), device="cuda")      # [sum | sum of squares][column][row]
         op.stats = stats.data_ptr()
     L.run_one(op, stream())
     torch.cuda.synchronize()
@@ -101,8 +101,8 @@ def test_igemm_fprop_dgrad_wgrad(case):
     out, stats = igemm(g, L.FPROP, dev(cl(x)), dev(w), (N, *yo, Co), want_stats=True)
     assert rel_err(uncl(out).cpu(), y_ref.detach()) < TOL
     flat = y_ref.detach().permute(0, 2, 3, 4, 1).reshape(-1, Co).double()
-    assert rel_err(stats[:, 0].double().sum(0).cpu(), flat.sum(0)) < TOL
-    assert rel_err(stats[:, 1].double().sum(0).cpu(), (flat * flat).sum(0)) < TOL
+    assert rel_err(stats[0].double().sum(1).cpu(), flat.sum(0)) < TOL
+    assert rel_err(stats[1].double().sum(1).cpu(), (flat * flat).sum(0)) < TOL
     # FPROP reading the NCDHW tensor in place
     xd = dev(x)
     st = (xd.stride(0), xd.stride(2), xd.stride(3), xd.stride(4), xd.stride(1))
@@ -186,7 +186,8 @@ def test_bn_finalize_and_backward(M, Cc):
     # statistics as the GEMM epilogue would deliver them: rows of partial (sum, sumsq)
     rows = 7
     chunks = torch.chunk(y, rows)
-    stats = torch.stack([torch.stack([c.sum(0), (c * c).sum(0)]) for c in chunks]).cuda()
+    stats = torch.stack([torch.stack([c.sum(0), (c * c).sum(0)]) for c in chunks])        # [rows][2][C]
+    stats = stats.permute(1, 2, 0).contiguous().cuda()                                    # the ABI layout [2][C][rows]
     d = {k: torch.empty(Cc, device="cuda") for k in ("mean", "invstd", "scale", "shift")}
     rm, rv, nbt = torch.zeros(Cc).cuda(), torch.ones(Cc).cuda(), torch.zeros((), dtype=torch.int64).cuda()
     gam, bet = dev(bn.weight.detach()), dev(bn.bias.detach())
