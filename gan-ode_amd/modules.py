@@ -119,10 +119,15 @@ class _GenPlan:
         self.gen, self.n, self.T, self.select, self.device = gen, n_traj, T, select, dev
         self.rows = n_traj if select else n_traj * T
         f32 = dict(dtype=torch.float32, device=dev)
-        self.x = torch.empty(n_traj, 16, **f32)
-        self.content = torch.empty(n_traj, 50, **f32)
+        # host-drawn inputs live in ONE device buffer [x 16 | content 50 | sel (int32 bits) 1] per trajectory block, so a
+        # call stages them with a single H2D copy
+        xs = self._x_shape(n_traj, T)
+        nx = int(np.prod(xs))
+        self._in = torch.zeros(nx + n_traj * 51, **f32)
+        self.x = self._in[:nx].view(xs)
+        self.content = self._in[nx:nx + n_traj * 50].view(n_traj, 50)
+        self.sel = self._in[nx + n_traj * 50:].view(torch.int32) if select else None
         self.traj = torch.empty(n_traj, T, 16, **f32)
-        self.sel = torch.zeros(n_traj, dtype=torch.int32, device=dev) if select else None
         tt = torch.linspace(0, 1, T).float()            # models/mocogan_ode.py:143 -- fp32 grid built on the host
         self.dt = (tt[1:] - tt[:-1]).to(dev) if T > 1 else torch.zeros(1, **f32)
         self.stack = ConvStack(gen._decoder_specs(self.rows), gen._decoder_params(), dev, owns_input=True,
@@ -132,9 +137,18 @@ class _GenPlan:
         self.busy = False
         # pinned staging ring for the host-drawn noise: a pageable H2D copy would block the host until the stream
         # drains (no host/GPU overlap between consecutive calls); slots are recycled behind an event
-        self._ring = [dict(x=torch.empty(n_traj, 16).pin_memory(), c=torch.empty(n_traj, 50).pin_memory(),
-                           s=torch.zeros(n_traj, dtype=torch.int32).pin_memory(), ev=None) for _ in range(4)]
+        self._ring = []
+        for _ in range(4):
+            buf = torch.zeros(nx + n_traj * 51).pin_memory()
+            self._ring.append(dict(buf=buf, x=buf[:nx].view(xs), c=buf[nx:nx + n_traj * 50].view(n_traj, 50),
+                                   s=buf[nx + n_traj * 50:].view(torch.int32), ev=None))
         self._ring_i = 0
+
+    @staticmethod
+    def _x_shape(n_traj, T):
+        """Shape of the host-drawn noise block: the ODE's initial states."""
+        return (n_traj, 16)
+
 
     def _ode_params(self):
         g = self.gen
@@ -194,11 +208,9 @@ class _GenPlan:
             slot["ev"].synchronize()
         slot["x"].copy_(x_host)
         slot["c"].copy_(content_host)
-        self.x.copy_(slot["x"], non_blocking=True)
-        self.content.copy_(slot["c"], non_blocking=True)
         if self.select:
             slot["s"].copy_(sel_host)
-            self.sel.copy_(slot["s"], non_blocking=True)
+        self._in.copy_(slot["buf"], non_blocking=True)
         if slot["ev"] is None:
             slot["ev"] = torch.cuda.Event()
         slot["ev"].record()
@@ -465,13 +477,14 @@ class _RnnGenPlan(_GenPlan):
     def __init__(self, gen, n_traj, T, select):
         super().__init__(gen, n_traj, T, select)
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.noise = torch.empty(T + 1, n_traj, 16, **f32)
+        self.noise = self.x        # [T+1, n, 16]: h_0 and the per-frame GRU inputs (staged by the base class)
         self.hp = torch.empty(n_traj, T, 16, **f32)
         self.nsteps = torch.zeros((n_traj + 63) // 64 * T, dtype=torch.int32, device=self.device)
         self.rnn_work = torch.empty(L.lib().gode_odernn_bwd_work_size(n_traj), **f32)
-        self._ring = [dict(x=torch.empty(T + 1, n_traj, 16).pin_memory(), c=torch.empty(n_traj, 50).pin_memory(),
-                           s=torch.zeros(n_traj, dtype=torch.int32).pin_memory(), ev=None) for _ in range(4)]
-        self.x = self.noise    # the staging code of the base class copies the noise stack into self.x
+
+    @staticmethod
+    def _x_shape(n_traj, T):
+        return (T + 1, n_traj, 16)
 
     def _rnn_params(self):
         g = self.gen
