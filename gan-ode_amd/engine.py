@@ -75,24 +75,6 @@ def _contig_strides(dims):
     return (d * h * w * c, h * w * c, w * c, c, 1)
 
 
-_SKEW = [0]
-
-
-def skewed_empty(dims, device, zero=False):
-    """Activation / gradient buffer whose start is offset by an odd multiple of 68 KiB inside its allocation.  A GEMM
-    that streams one tensor in and another out runs 10-15 % slower when the two start a large power of two apart
-    (measured: ConvT 128->64 338 us with output - source = 64.000 MiB, 314 us at +4 KiB, 292 us from +64 KiB on --
-    `scripts/exp_placement.py`), and the caching allocator hands out consecutive 2 MiB-aligned blocks, so same-shaped
-    activations land exactly that way.  The skew differs from buffer to buffer."""
-    n = 1
-    for d in dims:
-        n *= int(d)
-    _SKEW[0] = (_SKEW[0] + 1) % 13
-    off = (2 * _SKEW[0] + 1) * 17408                      # floats: odd multiples of 68 KiB, up to 1.7 MiB
-    base = (torch.zeros if zero else torch.empty)(n + 14 * 34816, dtype=torch.float32, device=device)
-    return base[off:off + n].view(*[int(d) for d in dims])
-
-
 class ConvStack:
     """Forward/backward programs of one conv stack at a fixed batch size.
 
@@ -110,11 +92,11 @@ class ConvStack:
         self.pack_cache = pack_cache if pack_cache is not None else {}
         lib = L.lib()
         f32 = dict(dtype=torch.float32, device=device)
-        self.x_in = skewed_empty(specs[0].in_dims(), device, zero=True) if owns_input else None
+        self.x_in = torch.zeros(specs[0].in_dims(), **f32) if owns_input else None
         # raw outputs of all but the last layer are plan-owned; the last is allocated per call
-        self.y = [skewed_empty(s.out_dims(), device) for s in specs[:-1]]
+        self.y = [torch.empty(s.out_dims(), **f32) for s in specs[:-1]]
         # activated copies a[l] = act(BN(y[l])) for layers whose consumer is a heavy GEMM (see gode_bn_apply)
-        self.a = [skewed_empty(s.out_dims(), device) if self._materialize(l) else None for l, s in enumerate(specs[:-1])]
+        self.a = [torch.empty(s.out_dims(), **f32) if self._materialize(l) else None for l, s in enumerate(specs[:-1])]
         self.out_dims = specs[-1].out_dims()
         self.wpack_f, self.wpack_b = [], [None] * self.nl
         self.stats, self.stat_rows = [], []
@@ -305,8 +287,8 @@ class ConvStack:
         lib = L.lib()
         f32 = dict(dtype=torch.float32, device=self.device)
         if self.g is None:
-            self.g = [skewed_empty(s.out_dims(), self.device) for s in self.specs]  # grad wrt raw/activated outputs
-            self.g_in = skewed_empty(self.specs[0].in_dims(), self.device)
+            self.g = [torch.empty(s.out_dims(), **f32) for s in self.specs]  # grad wrt raw/activated outputs
+            self.g_in = torch.empty(self.specs[0].in_dims(), **f32)
         ops, patch = [], {"dw": [], "dgamma": [], "dbeta": []}
         bpacks = []
         wg_work = 0
