@@ -5,7 +5,11 @@ import gan_ode_amd._lib as L
 from gan_ode_amd.engine import make_geom, stream_ptr
 lib = L.lib()
 R = 512
-for cin in (64, 128, 256, 512):
+_w = torch.randn(8192, 8192, device="cuda")
+for _ in range(40):      # ~100 ms of load first: the clock ramps for the first tens of ms of a process
+    _w = _w @ _w * 1e-4
+torch.cuda.synchronize()
+for cin in (512, 256, 128, 64, 64, 128, 256, 512):     # the first pass also warms the clock; read the second
     # convT cin->64 k4 s2 16x16 -> 32x32 as the conv whose dgrad it is: Ci=64, Co=cin
     g = make_geom(R, 64, cin, (1, 32, 32), (1, 16, 16), (1, 4, 4), (1, 2, 2), (0, 1, 1))
     src = torch.randn(R, 1, 16, 16, cin, device="cuda")
@@ -13,7 +17,7 @@ for cin in (64, 128, 256, 512):
     wp = torch.empty(lib.gode_pack_size(C.byref(g), L.DGRAD), device="cuda")
     L.check(lib.gode_pack_weights(C.byref(g), L.DGRAD, w.data_ptr(), wp.data_ptr(), None, 0, stream_ptr()))
     out = torch.empty(R, 1, 32, 32, 64, device="cuda")
-    op = L.IgemmOp(g=g, dir=L.DGRAD, act=0, epilogue=0, tile=2, src=src.data_ptr(), wpack=wp.data_ptr(), out=out.data_ptr())
+    op = L.IgemmOp(g=g, dir=L.DGRAD, act=0, epilogue=0, tile=int(os.environ.get("TILE", "2")), src=src.data_ptr(), wpack=wp.data_ptr(), out=out.data_ptr())
     rows = lib.gode_igemm_stats_rows(C.byref(op))
     stats = torch.empty(rows * 2 * 64 + 16, device="cuda"); op.stats = stats.data_ptr()
     st = stream_ptr()
