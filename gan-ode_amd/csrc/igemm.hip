@@ -720,6 +720,57 @@ __global__ void __launch_bounds__(256) conv_dot_kernel(const DotArgs d) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Pointwise (1x1x1, one phase) layers with <= 4 output columns and many positions: the MNIST generator's last layer
+// (ConvTranspose2d 64 -> 1, k1, a crop; models/mocogan_ode.py:82) fused with the previous BatchNorm+ReLU on load and
+// the tanh on store.  It only streams the input once (134 MB at batch 32), so it is an HBM pass, not a GEMM: Cg/4
+// lanes share one position (float4 each, shuffle reduction), 64/(Cg/4) positions per wave-iteration, grid-stride.
+// The MFMA path spent a 128x32 tile on one column: 44 us; this form runs at the copy rate of bn_apply.
+struct PwArgs { IgemmArgs a; FastDiv dMw, dMh, dMd; int32_t lpp; };
+
+__global__ void __launch_bounds__(256) conv_pointwise_kernel(const PwArgs d) {
+  const IgemmArgs& a = d.a;
+  const PhaseGeom& P = a.G.ph[0];
+  const int lane = threadIdx.x & 63, lpp = d.lpp, ppw = 64 / lpp;
+  const int sub = lane / lpp, ch = (lane - sub * lpp) * 4;
+  const int Ncols = a.G.Ncols;
+  const float neg = a.act == GODE_ACT_RELU ? 0.f : (a.act == GODE_ACT_LRELU ? 0.2f : 1.f);
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, w4[4];
+  if (a.scale) { sc = *reinterpret_cast<const f32x4*>(a.scale + ch); sh = *reinterpret_cast<const f32x4*>(a.shift + ch); }
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+    w4[n] = n < Ncols ? *reinterpret_cast<const f32x4*>(a.w + P.w_off + (int64_t)n * P.Kp + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t m0 = wave_id * ppw; m0 < P.M; m0 += nwaves * ppw) {
+    const int m = (int)m0 + sub;
+    const bool live = m < P.M;
+    const uint32_t mm = live ? (uint32_t)m : 0u;
+    const uint32_t t1 = fdiv(mm, d.dMw), qw = mm - t1 * P.Mw;
+    const uint32_t t2 = fdiv(t1, d.dMh), qh = t1 - t2 * P.Mh;
+    const uint32_t img = fdiv(t2, d.dMd), qd = t2 - img * P.Md;
+    const int id = (int)qd * a.G.Sd + P.Od, ih = (int)qh * a.G.Sh + P.Oh, iw = (int)qw * a.G.Sw + P.Ow;
+    const bool ok = live && (unsigned)id < (unsigned)a.G.Gd && (unsigned)ih < (unsigned)a.G.Gh && (unsigned)iw < (unsigned)a.G.Gw;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      v = *reinterpret_cast<const f32x4*>(a.src + (int)img * a.gsN + id * a.gsD + ih * a.gsH + iw * a.gsW + ch);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float u = v[e] * sc[e] + sh[e]; v[e] = fmaxf(u, u * neg); }
+    }
+    float acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = v[0] * w4[n][0] + v[1] * w4[n][1] + v[2] * w4[n][2] + v[3] * w4[n][3];
+    for (int o = lpp >> 1; o > 0; o >>= 1) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[n] += __shfl_xor(acc[n], o);
+    }
+    if (live && ch == 0) {
+      const int oo = ((((int)img * a.G.Xd + (int)qd * a.G.OSd + P.Pd) * a.G.Xh + (int)qh * a.G.OSh + P.Ph) * a.G.Xw +
+                      (int)qw * a.G.OSw + P.Pw) * Ncols;
+      for (int n = 0; n < Ncols; ++n) a.out[oo + n] = a.epilogue == GODE_EPI_TANH ? tanhf(acc[n]) : acc[n];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 enum { TILE_128x128 = 1, TILE_128x64 = 2, TILE_128x32 = 3, TILE_64x64 = 4, TILE_128x128_W8 = 5 };
 
 static int tile_bm(int tile) { return tile == TILE_64x64 ? 64 : 128; }
@@ -983,6 +1034,18 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
       if (G.ph[i].M > maxM) maxM = G.ph[i].M;
       if (G.ph[i].K < minK) minK = G.ph[i].K;
       kp_ok = kp_ok && G.ph[i].Kp == G.ph[i].K;
+    }
+    const int lpp = G.Cg / 4;
+    const bool one_tap = G.nphase == 1 && G.ph[0].K == G.Cg && G.ph[0].Td * G.ph[0].Th * G.ph[0].Tw == 1;
+    if (vec && kp_ok && one_tap && G.Ncols <= 4 && op->stats == nullptr && op->tile == 0 && maxM >= 4096 &&
+        (lpp == 4 || lpp == 8 || lpp == 16 || lpp == 32 || lpp == 64)) {
+      PwArgs D; D.a = A; D.lpp = lpp;
+      D.dMw = make_fastdiv((uint32_t)G.ph[0].Mw); D.dMh = make_fastdiv((uint32_t)G.ph[0].Mh); D.dMd = make_fastdiv((uint32_t)G.ph[0].Md);
+      int64_t blocks = ((int64_t)maxM + (64 / lpp) * 4 * 8 - 1) / ((64 / lpp) * 4 * 8);     // ~8 positions-groups per wave
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(conv_pointwise_kernel, dim3((int)blocks), dim3(256), 0, st, D);
+      GODE_LAUNCH_CHECK();
+      return 0;
     }
     if (vec && kp_ok && G.Ncols <= 4 && op->stats == nullptr && maxM <= 16384 && minK >= 512 && op->tile == 0) {
       DotArgs D; D.a = A; D.dCg = make_fastdiv((uint32_t)G.Cg);

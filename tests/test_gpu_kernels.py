@@ -82,6 +82,8 @@ CASES = [
     (64, 128, (1, 32, 32), (1, 4, 4), (1, 2, 2), (0, 1, 1), 6),    # decoder layer 3 at full width (128x64 FAST tile)
     (256, 512, (1, 8, 8), (1, 4, 4), (1, 2, 2), (0, 1, 1), 70),    # decoder layer 1 at full width, XCD-remapped grid
     (256, 512, (13, 5, 5), (2, 2, 2), (1, 2, 2), (0, 1, 1), 8),    # video-D layer 3 at full width (64x64 tile)
+    (1, 64, (1, 28, 28), (1, 1, 1), (1, 1, 1), (0, 2, 2), 8),      # MNIST generator head at full width: pointwise streaming kernel (DGRAD)
+    (2, 32, (1, 28, 28), (1, 1, 1), (1, 1, 1), (0, 2, 2), 9),      # same kernel, 2 columns, 8 lanes per position
 ]
 
 
