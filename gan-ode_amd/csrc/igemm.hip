@@ -770,6 +770,58 @@ __global__ void __launch_bounds__(256) conv_pointwise_kernel(const PwArgs d) {
   }
 }
 
+// Tiny-K layers (K = taps x channels, one phase; dispatched for K <= 4): the backward-data of the generator head (Conv
+// 1 -> 64, k1: K = 1) writes 64x more than it reads, so it is an output-bound HBM pass: the weight matrix sits in LDS as
+// [k][column], Ncols/4 lanes share a position (each gathers the K inputs itself -- same addresses, one broadcast -- and
+// owns 4 columns), grid-stride over positions.  Any source strides.  63 us on the padded-K MFMA path, 27 us here.
+__global__ void __launch_bounds__(256) conv_smallk_kernel(const PwArgs d) {
+  const IgemmArgs& a = d.a;
+  const PhaseGeom& P = a.G.ph[0];
+  const int Ncols = a.G.Ncols, Cg = a.G.Cg, K = P.K;
+  __shared__ __attribute__((aligned(16))) float wl[32 * 128];
+  for (int i = threadIdx.x; i < K * Ncols; i += 256) {
+    const int k = i / Ncols, n = i - k * Ncols;
+    wl[i] = a.w[P.w_off + (int64_t)n * P.Kp + k];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, lpp = d.lpp, ppw = 64 / lpp;
+  const int sub = lane / lpp, c4 = (lane - sub * lpp) * 4;
+  const float neg = a.act == GODE_ACT_RELU ? 0.f : (a.act == GODE_ACT_LRELU ? 0.2f : 1.f);
+  const bool xf = a.scale != nullptr;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t m0 = wave_id * ppw; m0 < P.M; m0 += nwaves * ppw) {
+    const int m = (int)m0 + sub;
+    if (m >= P.M) continue;
+    const uint32_t t1 = fdiv((uint32_t)m, d.dMw), qw = m - t1 * P.Mw;
+    const uint32_t t2 = fdiv(t1, d.dMh), qh = t1 - t2 * P.Mh;
+    const uint32_t img = fdiv(t2, d.dMd), qd = t2 - img * P.Md;
+    const int bd = (int)qd * a.G.Sd + P.Od, bh = (int)qh * a.G.Sh + P.Oh, bw = (int)qw * a.G.Sw + P.Ow;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (int jd = 0; jd < P.Td; ++jd)
+      for (int jh = 0; jh < P.Th; ++jh)
+        for (int jw = 0; jw < P.Tw; ++jw) {
+          const int id = bd + a.G.J * jd, ih = bh + a.G.J * jh, iw = bw + a.G.J * jw;
+          const bool ok = (unsigned)id < (unsigned)a.G.Gd && (unsigned)ih < (unsigned)a.G.Gh && (unsigned)iw < (unsigned)a.G.Gw;
+          const int off = (int)img * a.gsN + id * a.gsD + ih * a.gsH + iw * a.gsW;
+          for (int c = 0; c < Cg; ++c, ++k) {
+            float v = 0.f;
+            if (ok) {
+              v = a.src[off + c * a.gsC];
+              if (xf) v = v * a.scale[c] + a.shift[c];
+              v = fmaxf(v, v * neg);
+            }
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wl + k * Ncols + c4);
+            acc[0] += v * w[0]; acc[1] += v * w[1]; acc[2] += v * w[2]; acc[3] += v * w[3];
+          }
+        }
+    const int oo = ((((int)img * a.G.Xd + (int)qd * a.G.OSd + P.Pd) * a.G.Xh + (int)qh * a.G.OSh + P.Ph) * a.G.Xw +
+                    (int)qw * a.G.OSw + P.Pw) * Ncols;
+    if (a.epilogue == GODE_EPI_TANH) { acc[0] = tanhf(acc[0]); acc[1] = tanhf(acc[1]); acc[2] = tanhf(acc[2]); acc[3] = tanhf(acc[3]); }
+    *reinterpret_cast<f32x4*>(a.out + oo + c4) = acc;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 enum { TILE_128x128 = 1, TILE_128x64 = 2, TILE_128x32 = 3, TILE_64x64 = 4, TILE_128x128_W8 = 5 };
 
@@ -1046,6 +1098,21 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
       hipLaunchKernelGGL(conv_pointwise_kernel, dim3((int)blocks), dim3(256), 0, st, D);
       GODE_LAUNCH_CHECK();
       return 0;
+    }
+    {
+      const int nl = G.Ncols / 4;
+      // K <= 4 only: at K = 8 / 16 (first discriminator layers) the per-lane gather chain made it no faster than the
+      // padded MFMA path (24.9 vs 22 us, 15.7 vs 10 us); at K = 1 it is 27 us against 63 us
+      if (G.nphase == 1 && G.ph[0].K <= 4 && G.Ncols % 4 == 0 && G.Ncols <= 128 && op->stats == nullptr && op->tile == 0 &&
+          maxM >= 2048 && (nl == 4 || nl == 8 || nl == 16 || nl == 32) && ((uintptr_t)op->out % 16) == 0) {
+        PwArgs D; D.a = A; D.lpp = nl;
+        D.dMw = make_fastdiv((uint32_t)G.ph[0].Mw); D.dMh = make_fastdiv((uint32_t)G.ph[0].Mh); D.dMd = make_fastdiv((uint32_t)G.ph[0].Md);
+        int64_t blocks = ((int64_t)maxM + (64 / nl) * 4 * 4 - 1) / ((64 / nl) * 4 * 4);     // ~4 position groups per wave
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(conv_smallk_kernel, dim3((int)blocks), dim3(256), 0, st, D);
+        GODE_LAUNCH_CHECK();
+        return 0;
+      }
     }
     if (vec && kp_ok && G.Ncols <= 4 && op->stats == nullptr && maxM <= 16384 && minK >= 512 && op->tile == 0) {
       DotArgs D; D.a = A; D.dCg = make_fastdiv((uint32_t)G.Cg);

@@ -84,6 +84,9 @@ CASES = [
     (256, 512, (13, 5, 5), (2, 2, 2), (1, 2, 2), (0, 1, 1), 8),    # video-D layer 3 at full width (64x64 tile)
     (1, 64, (1, 28, 28), (1, 1, 1), (1, 1, 1), (0, 2, 2), 8),      # MNIST generator head at full width: pointwise streaming kernel (DGRAD)
     (2, 32, (1, 28, 28), (1, 1, 1), (1, 1, 1), (0, 2, 2), 9),      # same kernel, 2 columns, 8 lanes per position
+    (1, 64, (16, 28, 28), (2, 2, 2), (1, 2, 2), (0, 1, 1), 3),     # MNIST video-D layer 0 at full width: tiny-K kernel (K = 8), also strided
+    (1, 64, (1, 28, 28), (1, 4, 4), (1, 2, 2), (0, 1, 1), 12),     # MNIST image-D layer 0 at full width: tiny-K kernel (K = 16)
+    (2, 16, (1, 30, 30), (1, 3, 3), (1, 1, 1), (0, 1, 1), 3),      # tiny-K kernel with 2 channels x 9 taps, 4 lanes per position
 ]
 
 
