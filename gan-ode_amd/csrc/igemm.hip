@@ -720,44 +720,70 @@ __global__ void __launch_bounds__(256) conv_dot_kernel(const DotArgs d) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Pointwise (1x1x1, one phase) layers with <= 4 output columns and many positions: the MNIST generator's last layer
-// (ConvTranspose2d 64 -> 1, k1, a crop; models/mocogan_ode.py:82) fused with the previous BatchNorm+ReLU on load and
-// the tanh on store.  It only streams the input once (134 MB at batch 32), so it is an HBM pass, not a GEMM: Cg/4
-// lanes share one position (float4 each, shuffle reduction), 64/(Cg/4) positions per wave-iteration, grid-stride.
-// The MFMA path spent a 128x32 tile on one column: 44 us; this form runs at the copy rate of bn_apply.
-struct PwArgs { IgemmArgs a; FastDiv dMw, dMh, dMd; int32_t lpp; };
+// Layers with <= 4 output columns and many positions: the generators' last layers (MNIST: ConvTranspose2d 64 -> 1,
+// k1, a crop, models/mocogan_ode.py:82; UCF: ConvTranspose2d 64 -> 3, k4 s2, models/mocogan.py:213) with the previous
+// BatchNorm+ReLU fused on load and the tanh on store, and the input gradient of the first discriminator layer.  A
+// 32-column MFMA tile would be >= 87 % padding; these are streaming passes: Cg/4 lanes share one output position
+// (float4 of channels each, all taps in a loop, shuffle reduction at the end), 64/(Cg/4) positions per
+// wave-iteration, grid-stride, one grid row per stride phase, the phase's weight panel (<= 16 KB) in LDS.
+// MNIST head 44 -> 28 us; UCF head 224 -> ~65 us.
+#define PW_MAXW 4096
+struct PwArgs { IgemmArgs a; FastDiv dMw[GODE_MAX_PHASES], dMh[GODE_MAX_PHASES], dMd[GODE_MAX_PHASES]; int32_t lpp; };
 
+// ONE_TAP (1x1x1 layers, e.g. the MNIST head): the lane's weights live in registers, no LDS, no tap loop (28 us vs 34 us
+// through the general form on the 134 MB MNIST head input).
+template <bool ONE_TAP>
 __global__ void __launch_bounds__(256) conv_pointwise_kernel(const PwArgs d) {
   const IgemmArgs& a = d.a;
-  const PhaseGeom& P = a.G.ph[0];
+  const int ph = blockIdx.y;
+  const PhaseGeom& P = a.G.ph[ph];
+  const int Ncols = a.G.Ncols, Cg = a.G.Cg;
+  __shared__ __attribute__((aligned(16))) float wl[ONE_TAP ? 4 : PW_MAXW];      // [column][Kp]
+  if (!ONE_TAP) {
+    for (int i = threadIdx.x; i < Ncols * P.Kp; i += 256) wl[i] = a.w[P.w_off + i];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, lpp = d.lpp, ppw = 64 / lpp;
   const int sub = lane / lpp, ch = (lane - sub * lpp) * 4;
-  const int Ncols = a.G.Ncols;
   const float neg = a.act == GODE_ACT_RELU ? 0.f : (a.act == GODE_ACT_LRELU ? 0.2f : 1.f);
-  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, w4[4];
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
   if (a.scale) { sc = *reinterpret_cast<const f32x4*>(a.scale + ch); sh = *reinterpret_cast<const f32x4*>(a.shift + ch); }
+  const int ntap = ONE_TAP ? 1 : P.Td * P.Th * P.Tw;
+  f32x4 w1[4];
+  if (ONE_TAP) {
 #pragma unroll
-  for (int n = 0; n < 4; ++n)
-    w4[n] = n < Ncols ? *reinterpret_cast<const f32x4*>(a.w + P.w_off + (int64_t)n * P.Kp + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < 4; ++n)
+      w1[n] = n < Ncols ? *reinterpret_cast<const f32x4*>(a.w + P.w_off + (int64_t)n * P.Kp + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
   for (int64_t m0 = wave_id * ppw; m0 < P.M; m0 += nwaves * ppw) {
     const int m = (int)m0 + sub;
     const bool live = m < P.M;
     const uint32_t mm = live ? (uint32_t)m : 0u;
-    const uint32_t t1 = fdiv(mm, d.dMw), qw = mm - t1 * P.Mw;
-    const uint32_t t2 = fdiv(t1, d.dMh), qh = t1 - t2 * P.Mh;
-    const uint32_t img = fdiv(t2, d.dMd), qd = t2 - img * P.Md;
-    const int id = (int)qd * a.G.Sd + P.Od, ih = (int)qh * a.G.Sh + P.Oh, iw = (int)qw * a.G.Sw + P.Ow;
-    const bool ok = live && (unsigned)id < (unsigned)a.G.Gd && (unsigned)ih < (unsigned)a.G.Gh && (unsigned)iw < (unsigned)a.G.Gw;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ok) {
-      v = *reinterpret_cast<const f32x4*>(a.src + (int)img * a.gsN + id * a.gsD + ih * a.gsH + iw * a.gsW + ch);
+    const uint32_t t1 = fdiv(mm, d.dMw[ph]), qw = mm - t1 * P.Mw;
+    const uint32_t t2 = fdiv(t1, d.dMh[ph]), qh = t1 - t2 * P.Mh;
+    const uint32_t img = fdiv(t2, d.dMd[ph]), qd = t2 - img * P.Md;
+    const int bd = (int)qd * a.G.Sd + P.Od, bh = (int)qh * a.G.Sh + P.Oh, bw = (int)qw * a.G.Sw + P.Ow;
+    const int base = (int)img * a.gsN;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int jd = 0, jh = 0, jw = 0;
+    for (int t = 0; t < ntap; ++t) {
+      const int id = bd + a.G.J * jd, ih = bh + a.G.J * jh, iw = bw + a.G.J * jw;
+      const bool ok = live && (unsigned)id < (unsigned)a.G.Gd && (unsigned)ih < (unsigned)a.G.Gh && (unsigned)iw < (unsigned)a.G.Gw;
+      if (ok) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(a.src + base + id * a.gsD + ih * a.gsH + iw * a.gsW + ch);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float u = v[e] * sc[e] + sh[e]; v[e] = fmaxf(u, u * neg); }
+        for (int e = 0; e < 4; ++e) { const float u = v[e] * sc[e] + sh[e]; v[e] = fmaxf(u, u * neg); }
+        const float* wk = wl + t * Cg + ch;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          if (ONE_TAP || n < Ncols) {
+            const f32x4 w = ONE_TAP ? w1[n] : *reinterpret_cast<const f32x4*>(wk + n * P.Kp);
+            acc[n] += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+          }
+      }
+      if (++jw == P.Tw) { jw = 0; if (++jh == P.Th) { jh = 0; ++jd; } }
     }
-    float acc[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) acc[n] = v[0] * w4[n][0] + v[1] * w4[n][1] + v[2] * w4[n][2] + v[3] * w4[n][3];
     for (int o = lpp >> 1; o > 0; o >>= 1) {
 #pragma unroll
       for (int n = 0; n < 4; ++n) acc[n] += __shfl_xor(acc[n], o);
@@ -792,9 +818,9 @@ __global__ void __launch_bounds__(256) conv_smallk_kernel(const PwArgs d) {
   for (int64_t m0 = wave_id * ppw; m0 < P.M; m0 += nwaves * ppw) {
     const int m = (int)m0 + sub;
     if (m >= P.M) continue;
-    const uint32_t t1 = fdiv((uint32_t)m, d.dMw), qw = m - t1 * P.Mw;
-    const uint32_t t2 = fdiv(t1, d.dMh), qh = t1 - t2 * P.Mh;
-    const uint32_t img = fdiv(t2, d.dMd), qd = t2 - img * P.Md;
+    const uint32_t t1 = fdiv((uint32_t)m, d.dMw[0]), qw = m - t1 * P.Mw;
+    const uint32_t t2 = fdiv(t1, d.dMh[0]), qh = t1 - t2 * P.Mh;
+    const uint32_t img = fdiv(t2, d.dMd[0]), qd = t2 - img * P.Md;
     const int bd = (int)qd * a.G.Sd + P.Od, bh = (int)qh * a.G.Sh + P.Oh, bw = (int)qw * a.G.Sw + P.Ow;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int k = 0;
@@ -1088,14 +1114,21 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
       kp_ok = kp_ok && G.ph[i].Kp == G.ph[i].K;
     }
     const int lpp = G.Cg / 4;
-    const bool one_tap = G.nphase == 1 && G.ph[0].K == G.Cg && G.ph[0].Td * G.ph[0].Th * G.ph[0].Tw == 1;
-    if (vec && kp_ok && one_tap && G.Ncols <= 4 && op->stats == nullptr && op->tile == 0 && maxM >= 4096 &&
-        (lpp == 4 || lpp == 8 || lpp == 16 || lpp == 32 || lpp == 64)) {
+    int maxK = 0;
+    for (int i = 0; i < G.nphase; ++i) if (G.ph[i].Kp > maxK) maxK = G.ph[i].Kp;
+    const bool one_tap = G.nphase == 1 && G.ph[0].K == G.Cg;
+    // the multi-tap form needs many positions to beat the padded MFMA path (measured: M = 25 k slower, M >= 65 k faster)
+    if (vec && kp_ok && G.Ncols <= 4 && G.Ncols * maxK <= PW_MAXW && op->stats == nullptr && op->tile == 0 &&
+        maxM >= (one_tap ? 4096 : 65536) && (lpp == 4 || lpp == 8 || lpp == 16 || lpp == 32 || lpp == 64)) {
       PwArgs D; D.a = A; D.lpp = lpp;
-      D.dMw = make_fastdiv((uint32_t)G.ph[0].Mw); D.dMh = make_fastdiv((uint32_t)G.ph[0].Mh); D.dMd = make_fastdiv((uint32_t)G.ph[0].Md);
-      int64_t blocks = ((int64_t)maxM + (64 / lpp) * 4 * 8 - 1) / ((64 / lpp) * 4 * 8);     // ~8 positions-groups per wave
-      if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(conv_pointwise_kernel, dim3((int)blocks), dim3(256), 0, st, D);
+      for (int i = 0; i < G.nphase; ++i) {
+        D.dMw[i] = make_fastdiv((uint32_t)G.ph[i].Mw); D.dMh[i] = make_fastdiv((uint32_t)G.ph[i].Mh);
+        D.dMd[i] = make_fastdiv((uint32_t)G.ph[i].Md);
+      }
+      int64_t blocks = ((int64_t)maxM + (64 / lpp) * 4 * 8 - 1) / ((64 / lpp) * 4 * 8);     // ~8 position groups per wave
+      if (blocks > (one_tap ? 4096 : 2048)) blocks = one_tap ? 4096 : 2048;
+      if (one_tap) hipLaunchKernelGGL(conv_pointwise_kernel<true>, dim3((int)blocks, 1), dim3(256), 0, st, D);
+      else hipLaunchKernelGGL(conv_pointwise_kernel<false>, dim3((int)blocks, G.nphase), dim3(256), 0, st, D);
       GODE_LAUNCH_CHECK();
       return 0;
     }
@@ -1106,7 +1139,7 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
       if (G.nphase == 1 && G.ph[0].K <= 4 && G.Ncols % 4 == 0 && G.Ncols <= 128 && op->stats == nullptr && op->tile == 0 &&
           maxM >= 2048 && (nl == 4 || nl == 8 || nl == 16 || nl == 32) && ((uintptr_t)op->out % 16) == 0) {
         PwArgs D; D.a = A; D.lpp = nl;
-        D.dMw = make_fastdiv((uint32_t)G.ph[0].Mw); D.dMh = make_fastdiv((uint32_t)G.ph[0].Mh); D.dMd = make_fastdiv((uint32_t)G.ph[0].Md);
+        D.dMw[0] = make_fastdiv((uint32_t)G.ph[0].Mw); D.dMh[0] = make_fastdiv((uint32_t)G.ph[0].Mh); D.dMd[0] = make_fastdiv((uint32_t)G.ph[0].Md);
         int64_t blocks = ((int64_t)maxM + (64 / nl) * 4 * 4 - 1) / ((64 / nl) * 4 * 4);     // ~4 position groups per wave
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(conv_smallk_kernel, dim3((int)blocks), dim3(256), 0, st, D);

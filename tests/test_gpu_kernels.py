@@ -87,6 +87,9 @@ CASES = [
     (1, 64, (16, 28, 28), (2, 2, 2), (1, 2, 2), (0, 1, 1), 3),     # MNIST video-D layer 0 at full width: tiny-K kernel (K = 8), also strided
     (1, 64, (1, 28, 28), (1, 4, 4), (1, 2, 2), (0, 1, 1), 12),     # MNIST image-D layer 0 at full width: tiny-K kernel (K = 16)
     (2, 16, (1, 30, 30), (1, 3, 3), (1, 1, 1), (0, 1, 1), 3),      # tiny-K kernel with 2 channels x 9 taps, 4 lanes per position
+    (3, 64, (1, 64, 64), (1, 4, 4), (1, 2, 2), (0, 1, 1), 5),      # UCF generator head at full width (DGRAD, 3 columns, 4 phases x 4 taps): streaming kernel
+    (64, 3, (1, 32, 32), (1, 4, 4), (1, 2, 2), (0, 1, 1), 20),     # few-column FPROP with 16 taps (K = 1024) through the same kernel
+    (1, 32, (6, 28, 28), (2, 2, 2), (1, 2, 2), (0, 1, 1), 4),      # video-D layer-0 input gradient shape (DGRAD, 1 column, 8 lanes per position)
 ]
 
 
