@@ -24,7 +24,9 @@ SO = os.path.join(REPO, "tests", "hostcheck", "libgeomcheck.so")
 def hc():
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(
             os.path.join(REPO, "gan-ode_amd", "csrc", "conv_geom.h"))):
-        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-std=c++17", SRC, "-o", SO])
+        # UBSan in trap mode (no runtime library needed in a ctypes-loaded .so): signed overflow, bad shifts, OOB on fixed arrays
+        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-std=c++17", "-fsanitize=undefined,bounds",
+                               "-fsanitize-undefined-trap-on-error", SRC, "-o", SO])
     lib = C.CDLL(SO)
     lib.hc_igemm.argtypes = [C.c_void_p] * 7
     lib.hc_wgrad.argtypes = [C.c_void_p] * 5
