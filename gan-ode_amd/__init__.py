@@ -7,16 +7,13 @@ anything does, and there is no fallback path.
 from . import _lib
 from .modules import (Noise, ODEFunc, PatchImageDiscriminator, VideoDiscriminator, VideoGenerator,
                       VideoGeneratorMNIST, VideoGeneratorMNISTODE, VideoGeneratorMNISTODERNN)
-from .train import (FusedAdam, GanTrainer, bce_with_logits_const, build_mnist, build_ucf, freeze_host_gc,
-                    host_cpu_quota, limit_host_threads, train_step)
+from .train import (FusedAdam, GanTrainer, bce_with_logits_const, bce_with_logits_pair, build_mnist, build_ucf,
+                    freeze_host_gc, host_cpu_quota, limit_host_threads, train_step, unit_grad)
 
 __all__ = ["Noise", "ODEFunc", "PatchImageDiscriminator", "VideoDiscriminator", "VideoGenerator",
            "VideoGeneratorMNIST", "VideoGeneratorMNISTODE", "VideoGeneratorMNISTODERNN", "FusedAdam", "GanTrainer", "bce_with_logits_const",
-           "build_mnist", "build_ucf", "train_step", "host_cpu_quota", "limit_host_threads", "freeze_host_gc", "_lib"]
+           "bce_with_logits_pair", "unit_grad", "build_mnist", "build_ucf", "train_step", "host_cpu_quota", "limit_host_threads", "freeze_host_gc", "_lib"]
 
-import os as _os
-
-if _os.environ.get("GODE_KEEP_TORCH_THREADS") != "1":
-    # see train.limit_host_threads: an intra-op pool larger than the container's CPU quota gets the whole process
-    # throttled (75-90 ms stalls); opt out with GODE_KEEP_TORCH_THREADS=1
-    limit_host_threads()
+# Process-global host tuning is opt-in (nothing happens at import): call limit_host_threads() once at start-up when
+# torch's intra-op pool is larger than the container's CPU quota (see its docstring; bench.py and tests/conftest.py
+# do), and freeze_host_gc() after warm-up in long loops (GanTrainer(freeze_gc=True) does it after its 2nd iteration).

@@ -51,7 +51,7 @@ class BnFinalizeOp(C.Structure):
 class BnBwdOp(C.Structure):
     _fields_ = [("g", ptr), ("y", ptr), ("M", i64), ("C", i32), ("act", i32), ("gamma", ptr), ("mean", ptr),
                 ("invstd", ptr), ("scale", ptr), ("shift", ptr), ("dgamma", ptr), ("dbeta", ptr), ("work", ptr),
-                ("accumulate", i32), ("pad_", i32)]
+                ("accumulate", i32), ("eval_mode", i32), ("gin", ptr)]
     KIND = OP_BN_BWD
 
 
@@ -174,6 +174,28 @@ def check(rc, what="gode call"):
         raise RuntimeError(f"{what} failed with code {rc}" + (" (hipError)" if rc > 0 else " (argument/shape error)"))
 
 
+# Measurement hook (bench.py's iteration roofline / per-class time split): when TRACE is a list, every op is launched
+# on its own between two stream events and (op, start_event, end_event) is appended.  None (default): no overhead
+# beyond one comparison per program.
+TRACE = None
+
+
+def _traced(op, stream, launch):
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    TRACE.append((op, e0, e1))
+
+
+def call(tag, launch):
+    """Entry points that take no op struct (gode_adam_multi, gode_scale): `tag` stands in for the op in TRACE."""
+    if TRACE is not None:
+        return _traced(tag, None, launch)
+    launch()
+
+
 class Program:
     """A fixed list of op structs executed by one gode_run call.  The structs stay alive (and patchable) here."""
 
@@ -185,10 +207,24 @@ class Program:
         self.n = n
 
     def run(self, stream):
+        if TRACE is not None:
+            for op in self.ops:
+                run_one(op, stream)
+            return
         check(lib().gode_run(self.kinds, self.ptrs, self.n, stream), "gode_run")
 
 
 def run_one(op, stream):
+    if op.KIND == OP_PACK:
+        launch = lambda: check(lib().gode_pack_weights(C.byref(op.g), op.dir, op.w, op.wpack, op.co_perm, op.co_canon,  # noqa: E731
+                                                       stream), "gode_pack_weights")
+        return _traced(op, stream, launch) if TRACE is not None else launch()
+    if TRACE is not None:
+        return _traced(op, stream, lambda: _run_one(op, stream))
+    _run_one(op, stream)
+
+
+def _run_one(op, stream):
     fn = {OP_IGEMM: "gode_igemm", OP_WGRAD: "gode_wgrad", OP_BN_FINALIZE: "gode_bn_finalize", OP_BN_BWD: "gode_bn_bwd",
           OP_ODE_FWD: "gode_ode_fwd", OP_ODE_BWD: "gode_ode_bwd", OP_BCE: "gode_bce_logits",
           OP_ADAM: "gode_adam_l2", OP_ODERNN_FWD: "gode_odernn_fwd", OP_ODERNN_BWD: "gode_odernn_bwd",

@@ -115,8 +115,9 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const gode_bn_bwd_op
     const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + c), is = *reinterpret_cast<const f32x4*>(a.invstd + c);
     const int64_t r0 = (int64_t)blockIdx.x * BNB_ROWS;
     const int64_t r1 = r0 + BNB_ROWS < a.M ? r0 + BNB_ROWS : a.M;
+    const float* gsrc = a.gin ? a.gin : a.g;
     for (int64_t r = r0 + rlane; r < r1; r += rl) {
-      const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + r * a.C + c);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + r * a.C + c);
       const f32x4 y = *reinterpret_cast<const f32x4*>(a.y + r * a.C + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -164,18 +165,20 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const gode_bn_bwd_
     const double g = a.gamma ? (double)a.gamma[c] : 1.0, is = (double)a.invstd[c], mu = (double)a.mean[c];
     const double k = g * is;
     float* coef = a.work + (int64_t)rows * 4 * a.C;
-    coef[c] = (float)k;                                   // * g_z
-    coef[a.C + c] = (float)(k * is * red[1][0] * invM);   // * (mean - y)
-    coef[2 * a.C + c] = (float)(k * red[0][0] * invM);    // subtracted constant
+    // eval mode (running statistics are constants of the forward): g_y = gamma*invstd * g_z, no batch terms
+    coef[c] = (float)k;                                                      // * g_z
+    coef[a.C + c] = a.eval_mode ? 0.f : (float)(k * is * red[1][0] * invM);  // * (mean - y)
+    coef[2 * a.C + c] = a.eval_mode ? 0.f : (float)(k * red[0][0] * invM);   // subtracted constant
   }
 }
 
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const gode_bn_bwd_op a, int rows) {
   const int64_t n4 = a.M * a.C / 4;
   const float* coef = a.work + (int64_t)rows * 4 * a.C;
+  const float* gsrc = a.gin ? a.gin : a.g;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const int c = (int)((i * 4) % a.C);
-    f32x4 g = *reinterpret_cast<const f32x4*>(a.g + i * 4);
+    f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + i * 4);
     const f32x4 y = *reinterpret_cast<const f32x4*>(a.y + i * 4);
     const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c), sh = *reinterpret_cast<const f32x4*>(a.shift + c);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + c);
@@ -190,9 +193,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const gode_bn_bwd_op 
 }
 
 // no BatchNorm: g *= act'(y) (or tanh-from-output), any C
-__global__ void __launch_bounds__(256) act_bwd_kernel(float* g, const float* y, int64_t n, int act) {
+__global__ void __launch_bounds__(256) act_bwd_kernel(float* g, const float* gin, const float* y, int64_t n, int act) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    g[i] = gz_of(g[i], y[i], 1.f, 0.f, act);
+    g[i] = gz_of(gin[i], y[i], 1.f, 0.f, act);
 }
 
 extern "C" int64_t gode_bn_bwd_work_size(int64_t M, int32_t C) {
@@ -209,8 +212,8 @@ extern "C" int gode_bn_bwd(const gode_bn_bwd_op* op, void* stream) {
   if (!op || !op->g || !op->y || op->M <= 0 || op->C <= 0) return GODE_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (!op->mean) {
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(op->M * op->C)), dim3(256), 0, st, op->g, op->y,
-                       op->M * op->C, op->act);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(op->M * op->C)), dim3(256), 0, st, op->g,
+                       op->gin ? op->gin : op->g, op->y, op->M * op->C, op->act);
     GODE_LAUNCH_CHECK();
     return 0;
   }

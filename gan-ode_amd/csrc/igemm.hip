@@ -493,6 +493,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
     const int buf = (nslab - 1) & 1;
     mma_group(buf, 0); mma_group(buf, 1); mma_group(buf, 2); mma_group(buf, 3);
     __syncthreads();
+#ifdef GODE_ABLATION_BUILD   // timing-only bodies (WRONG results); never defined for libgode.so (gan-ode_amd/build.py)
   } else if (a.stagger == -1) {        // ABLATION (timing only, wrong results): MFMA + LDS reads, no staging, no barriers
     stageA(0); stageB(0);
     __syncthreads();
@@ -506,6 +507,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
     __syncthreads();
     for (int s = 0; s + 1 < nslab; ++s) { __syncthreads(); fetch(s + 1); mma_group(0, 0); mma_group(0, 1); mma_group(0, 2); mma_group(0, 3); __syncthreads(); }
     asm volatile("" :: "v"(ra[0][0]), "v"(rb[0][0]));
+#endif
   } else {
     for (int s = 0; s + 1 < nslab; ++s) {
       stageA(0);
@@ -1026,6 +1028,9 @@ static int launch(IgemmArgs& A, bool vec, int max_mblk, bool double_buf, const S
     A.MB = MB; A.NB = NB; A.xcd_mode = 0;
     static const char* senv = getenv("GODE_IGEMM_STAGGER");
     A.stagger = senv ? atoi(senv) : 0;
+#ifndef GODE_ABLATION_BUILD
+    if (A.stagger < 0) A.stagger = 0;   // the negative (ablation) selectors only exist in -DGODE_ABLATION_BUILD builds
+#endif
     static const char* xenv = getenv("GODE_IGEMM_XCD");
     const int force = xenv ? atoi(xenv) : -1;
     const int64_t wbytes = gode_pack_floats(A.G) * 4;

@@ -87,6 +87,8 @@ class ConvStack:
         self.nl = len(specs)
         self.momentum, self.eps = momentum, eps
         self.busy = False
+        self.generation = 0      # bumped by every forward; an autograd node checks it before using the plan's buffers
+        self._fwd_training = True
         # packed weight panels do not depend on the batch size: all plans of one module share them (and the record
         # of which weight version each panel was packed from)
         self.pack_cache = pack_cache if pack_cache is not None else {}
@@ -120,7 +122,7 @@ class ConvStack:
                 self.mean.append(None); self.invstd.append(None); self.scale.append(None); self.shift.append(None)
         self._ig_work = None    # split-K workspace shared by the plan's igemm ops (they run back to back)
         self._fwd = {}          # training flag -> Program
-        self._bwd = {}          # (need_input_grad, need_param_grad) -> Program (D steps and G steps alternate)
+        self._bwd = {}          # (need_input_grad, need_param_grad, forward was train-mode) -> Program
         self.g = None           # gradient buffers (lazy)
         self._param_ptrs = None
 
@@ -210,6 +212,11 @@ class ConvStack:
             self._fwd, self._bwd, self._param_ptrs = {}, {}, ptrs
             self._all_igemm = []
 
+    def invalidate_packs(self):
+        """Forget which weight versions the packed panels were built from (next pass re-packs all of them)."""
+        for k in [k for k in self.pack_cache if k[0] == "ver"]:
+            del self.pack_cache[k]
+
     def weights_key(self):
         """Changes whenever any conv weight may have changed: torch's in-place version counter (torch optimisers,
         load_state_dict) plus the counter FusedAdam bumps (it updates through raw pointers)."""
@@ -272,6 +279,8 @@ class ConvStack:
             pre_ops_program.run(st)
         prog.run(st)
         self.out = out
+        self.generation += 1
+        self._fwd_training = training
         return out
 
     # -- backward ------------------------------------------------------------------------------------------
@@ -283,21 +292,25 @@ class ConvStack:
                 n += p.gamma.numel() + p.beta.numel()
         return n
 
-    def _build_bwd(self, need_input_grad: bool, need_param_grad: bool = True):
+    def _build_bwd(self, need_input_grad: bool, need_param_grad: bool = True, training: bool = True):
         lib = L.lib()
         f32 = dict(dtype=torch.float32, device=self.device)
         if self.g is None:
             self.g = [torch.empty(s.out_dims(), **f32) for s in self.specs]  # grad wrt raw/activated outputs
-            self.g_in = torch.empty(self.specs[0].in_dims(), **f32)
+            self.g_in = None
         ops, patch = [], {"dw": [], "dgamma": [], "dbeta": []}
         bpacks = []
         wg_work = 0
         bn_work = 0
         last = self.specs[-1]
+        # ops that read the upstream gradient: patched per call to the caller's tensor when it is contiguous (no
+        # staging copy); with a tanh epilogue only its backward reads it (and writes g[-1] for the others)
+        readers = patch["gout_readers"] = []
         if last.epilogue == L.EPI_TANH:
             M = self._count(self.nl - 1)
             op = L.BnBwdOp(g=dptr(self.g[-1]), y=None, M=M, C=last.out_dims()[4], act=L.ACT_TANH_OUT)
             patch["tanh"] = op
+            readers.append((op, "gin"))
             ops.append(op)
         for l in range(self.nl - 1, -1, -1):
             s, p = self.specs[l], self.params[l]
@@ -316,6 +329,8 @@ class ConvStack:
                 patch["dw"].append((l, w))
                 if l == 0:
                     patch["wgrad0"] = w
+                if l == self.nl - 1 and "tanh" not in patch:
+                    readers.append((w, "y" if s.fwd_dir == L.FPROP else "x"))
                 ops.append(w)
             # input gradient
             if l > 0 or need_input_grad:
@@ -324,15 +339,21 @@ class ConvStack:
                 bpacks.append((l, rev, L.PackOp(g=s.geom, dir=rev, co_canon=0, w=dptr(p.weight),
                                                 wpack=dptr(self.wpack_b[l]), co_perm=dptr(s.co_perm))))
                 dst = self.g_in if l == 0 else self.g[l - 1]
-                ops.append(L.IgemmOp(g=s.geom, dir=rev, act=L.ACT_NONE, epilogue=L.EPI_RAW, tile=0, src=dptr(self.g[l]),
-                                     wpack=dptr(self.wpack_b[l]), out=dptr(dst)))
+                ig = L.IgemmOp(g=s.geom, dir=rev, act=L.ACT_NONE, epilogue=L.EPI_RAW, tile=0, src=dptr(self.g[l]),
+                               wpack=dptr(self.wpack_b[l]), out=dptr(dst))
+                if l == self.nl - 1 and "tanh" not in patch:
+                    readers.append((ig, "src"))
+                if l == 0:
+                    patch["dgrad0"] = ig        # its output (the input gradient) is allocated per call
+                ops.append(ig)
             if l > 0:
                 sp, pp = self.specs[l - 1], self.params[l - 1]
                 M, Cc = self._count(l - 1), sp.out_dims()[4]
                 if sp.has_bn:
                     b = L.BnBwdOp(g=dptr(self.g[l - 1]), y=dptr(self.y[l - 1]), M=M, C=Cc, act=sp.act,
                                   gamma=dptr(pp.gamma), mean=dptr(self.mean[l - 1]), invstd=dptr(self.invstd[l - 1]),
-                                  scale=dptr(self.scale[l - 1]), shift=dptr(self.shift[l - 1]), accumulate=0)
+                                  scale=dptr(self.scale[l - 1]), shift=dptr(self.shift[l - 1]), accumulate=0,
+                                  eval_mode=0 if training else 1)
                     bn_work = max(bn_work, lib.gode_bn_bwd_work_size(M, Cc))
                     if need_param_grad:
                         patch["dgamma"].append((l - 1, b))
@@ -368,18 +389,31 @@ class ConvStack:
         into: optional per-layer [(weight_grad, gamma_grad, beta_grad, accumulate)] -- the kernels then write (or
         add to) those caller-owned tensors directly and (None, None, g_in) is returned."""
         self._refresh()
-        key = (need_input_grad, need_param_grad)
+        # an eval-mode forward normalised with the running statistics: its backward has no batch-statistics terms
+        key = (need_input_grad, need_param_grad, self._fwd_training)
         if key not in self._bwd:
-            self._bwd[key] = self._build_bwd(need_input_grad, need_param_grad)
+            self._bwd[key] = self._build_bwd(need_input_grad, need_param_grad, self._fwd_training)
         prog, patch = self._bwd[key]
         self._run_stale_packs(patch["packs"], stream_ptr())
-        self.g[-1].copy_(gout)
+        if gout.is_contiguous() and gout.numel() == self.g[-1].numel():
+            gp = gout.data_ptr()                 # read in place (the kernels never write through these pointers)
+        else:
+            self.g[-1].copy_(gout)               # a strided upstream gradient (not produced by the training loop)
+            gp = self.g[-1].data_ptr()
+        for op, field in patch["gout_readers"]:
+            setattr(op, field, gp)
         if "tanh" in patch:
             patch["tanh"].y = self.out.data_ptr()
+        g_in = None
+        if need_input_grad:
+            # the input gradient leaves the plan (autograd hands it on), so it gets its own tensor per call
+            g_in = torch.empty(self.specs[0].in_dims(), dtype=torch.float32, device=self.device)
+            patch["dgrad0"].out = g_in.data_ptr()
+        self.g_in = g_in
         if not need_param_grad:
             prog.run(stream_ptr())
             self.busy = False
-            return None, None, (self.g_in if need_input_grad else None)
+            return None, None, g_in
         if into is not None:
             per = {l: t for l, t in enumerate(into)}
             for l, w in patch["dw"]:

@@ -32,7 +32,13 @@ def _require_gpu(t: torch.Tensor, what: str):
 
 class _Pool:
     """Plans own their activation buffers; a plan stays checked out between a forward that saved state for autograd
-    and its backward, so two overlapping passes of the same shape (D(real), D(fake)) get distinct plans."""
+    and its backward, so two overlapping passes of the same shape (D(real), D(fake)) get distinct plans.  A forward
+    whose backward never comes (loss dropped) gives its plan back when its autograd node is freed (_Lease).  Every
+    forward bumps the plan's generation and its autograd node remembers it: a backward that arrives after the plan's
+    buffers were reused (retain_graph second pass, or more than MAX_PLANS forwards of one shape kept alive) raises
+    instead of computing on overwritten activations."""
+
+    MAX_PLANS = 6
 
     def __init__(self):
         self.plans = {}
@@ -43,7 +49,8 @@ class _Pool:
         for p in lst:
             if not p.busy:
                 return p
-        if len(lst) >= 6:          # forwards whose backward never came (loss dropped): recycle the oldest plan
+        if len(lst) >= self.MAX_PLANS:
+            # all checked out: reuse the oldest; its pending backward (if it ever comes) fails the generation check
             p = lst.pop(0)
             p.busy = False
             lst.append(p)
@@ -55,6 +62,34 @@ class _Pool:
     def clear(self):
         self.plans.clear()
         self.pack_cache.clear()
+
+
+class _Lease:
+    """Held by an autograd node: identifies the forward (plan generation) whose buffers the node will need, and gives
+    the plan back if the node dies without having run its backward."""
+
+    __slots__ = ("plan", "generation")
+
+    def __init__(self, plan):
+        self.plan, self.generation = plan, _plan_generation(plan)
+
+    def check(self, what):
+        if _plan_generation(self.plan) != self.generation:
+            raise RuntimeError(
+                f"{what}: the activation buffers of this forward pass were reused by a later forward of the same shape "
+                "before backward() ran (a second backward through a retained graph, or more than "
+                f"{_Pool.MAX_PLANS} grad-enabled forwards of one shape kept alive at once); run the forward again")
+
+    def __del__(self):
+        try:
+            if self.plan.busy and _plan_generation(self.plan) == self.generation:
+                self.plan.busy = False
+        except Exception:
+            pass
+
+
+def _plan_generation(plan):
+    return plan.stack.generation if hasattr(plan, "stack") else plan.generation
 
 
 # ==================================================================================================================
@@ -172,12 +207,15 @@ class _GenPlan:
             self._ode_ptrs = ptrs
             op = L.OdeParams(*ptrs[:8])
             prenet = 0 if ps[0] is None else 1
+            zbuf = getattr(self, "_zbuf", None)
+            zbuf = self.stack.x_in if zbuf is None else zbuf
+            zcols = getattr(self, "_zcols", Z_COLS)
             self.fwd_op = L.OdeFwdOp(p=op, x=dptr(self.x), content=dptr(self.content), dt=dptr(self.dt),
-                                     sel_t=dptr(self.sel), z=dptr(self.stack.x_in), traj=dptr(self.traj), N=self.n,
-                                     T=self.T, substeps=self.gen.ode_substeps, prenet=prenet, zcols=Z_COLS)
+                                     sel_t=dptr(self.sel), z=dptr(zbuf), traj=dptr(self.traj), N=self.n,
+                                     T=self.T, substeps=self.gen.ode_substeps, prenet=prenet, zcols=zcols)
             self.bwd_op = L.OdeBwdOp(p=op, x=dptr(self.x), traj=dptr(self.traj), dt=dptr(self.dt),
                                      sel_t=dptr(self.sel), gz=None, work=dptr(self.ode_work), grads=None, N=self.n,
-                                     T=self.T, substeps=self.gen.ode_substeps, prenet=prenet, accumulate=0, zcols=Z_COLS)
+                                     T=self.T, substeps=self.gen.ode_substeps, prenet=prenet, accumulate=0, zcols=zcols)
             self._grid = None
             if self.gen.ode_method == "dopri5":
                 # torchdiffeq's adaptive solver over the output times; the adjoint is the same continuous adjoint,
@@ -261,11 +299,13 @@ class _GenFn(torch.autograd.Function):
     def forward(ctx, plan, x_host, content_host, sel_host, training, keep, n_dec, *params):
         out = plan.forward(x_host, content_host, sel_host, training, keep)
         ctx.plan, ctx.n_dec, ctx.n_params = plan, n_dec, len(params)
+        ctx.lease = _Lease(plan)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         plan = ctx.plan
+        ctx.lease.check(type(plan.gen).__name__)
         arena = getattr(plan.gen, "_gode_arena", None)
         if arena is not None and arena.active:
             plan.backward(gout, arena)
@@ -278,6 +318,45 @@ class _GenFn(torch.autograd.Function):
                 grads += [gv, bv]
         assert len(grads) == ctx.n_dec and len(motion) == ctx.n_params - ctx.n_dec
         return (None, None, None, None, None, None, None, *grads, *motion)
+
+
+class _LatentFn(torch.autograd.Function):
+    """sample_z_m as its own autograd node: the fused ODE kernel alone, trajectory written as [N][T][16] = the
+    reference's transpose(0,1).reshape(-1,16) row order."""
+
+    @staticmethod
+    def forward(ctx, gen, x_host, n, T, *params):
+        dev = gen.main[0].weight.device
+        lp = _GenPlan.__new__(_GenPlan)           # only the ODE half of a plan: no decoder buffers
+        lp.gen, lp.n, lp.T, lp.select, lp.device = gen, n, T, False, dev
+        f32 = dict(dtype=torch.float32, device=dev)
+        lp.x = x_host.to(dev)
+        lp.content, lp.sel = None, None
+        lp.traj = torch.empty(n, T, 16, **f32)
+        tt = torch.linspace(0, 1, T).float()
+        lp.dt = (tt[1:] - tt[:-1]).to(dev) if T > 1 else torch.zeros(1, **f32)
+        lp._z = torch.empty(n * T, 68, **f32)     # the kernel's latent-row output (unused columns stay unwritten)
+        lp.ode_work = torch.empty(L.lib().gode_ode_bwd_work_size(n), **f32)
+        lp._ode_ptrs = None
+        lp._zbuf, lp._zcols = lp._z, 68
+        lp._programs()
+        lp.fwd_prog.run(stream_ptr())
+        ctx.lp = lp
+        return lp.traj.view(n * T, 16)
+
+    @staticmethod
+    def backward(ctx, gout):
+        lp = ctx.lp
+        g = gout.contiguous()
+        grads = torch.empty(L.ODE_NPARAM, dtype=torch.float32, device=lp.device)
+        op = lp.bwd_op
+        op.gz, op.zcols, op.grads, op.accumulate = g.data_ptr(), 16, grads.data_ptr(), 0
+        L.run_one(op, stream_ptr())
+        offs = [(0, 1024, (64, 16)), (1024, 64, (64,)), (1088, 1024, (16, 64)), (2112, 16, (16,)),
+                (2128, 256, (16, 16)), (2384, 16, (16,)), (2400, 256, (16, 16)), (2656, 16, (16,))]
+        if lp._ode_ptrs[0] is None:
+            offs = offs[4:]
+        return (None, None, None, None, *[grads[o:o + k].view(shp) for o, k, shp in offs])
 
 
 class VideoGenerator(nn.Module):
@@ -316,8 +395,27 @@ class VideoGenerator(nn.Module):
             # keep the failure mode but say why.
             raise TypeError("ODEFunc.__init__() missing 1 required positional argument: 'dim_hidden' "
                             "(pass dim_hidden=16; ucf_moco_ode.py:80 omits it and fails the same way)")
-        self.ode_fn = ode_fn(dim=self.dim_z_motion, dim_hidden=dim_hidden)
+        self.ode_fn = self._make_ode_fn(ode_fn, dim_hidden)
         self.linear = self._make_prenet(linear)
+
+    def _make_ode_fn(self, ode_fn, dim_hidden):
+        """The fused RK4 / adjoint kernels hard-code ODEFunc's 16 -> 16 -> 16 tanh MLP (one MFMA tile per mat-vec):
+        anything else would be integrated with the wrong right-hand side, so it is refused here."""
+        hid = dim_hidden if dim_hidden else self.dim_z_motion
+        if hid != 16:
+            raise NotImplementedError(f"dim_hidden={hid}: libgode's fused ODE kernels are specialised for the "
+                                      "16-16-16 ODEFunc of mnist_moco_ode.py:78 (dim_hidden=None -> dim_z_motion=16)")
+        if not (isinstance(ode_fn, type) and issubclass(ode_fn, ODEFunc)):
+            raise NotImplementedError("ode_fn must be gan_ode_amd's ODEFunc (W2 tanh(W1 x + b1) + b2, "
+                                      "models/mocogan_ode.py:6-17): the right-hand side is evaluated inside the "
+                                      "fused HIP kernels, an arbitrary Python callable cannot be")
+        fn = ode_fn(dim=self.dim_z_motion, dim_hidden=hid)
+        lin = [m for m in fn.fn] if hasattr(fn, "fn") else []
+        if not (len(lin) == 3 and isinstance(lin[0], nn.Linear) and isinstance(lin[1], nn.Tanh)
+                and isinstance(lin[2], nn.Linear) and tuple(lin[0].weight.shape) == (16, 16)
+                and tuple(lin[2].weight.shape) == (16, 16)):
+            raise NotImplementedError("ode_fn.fn must be Sequential(Linear(16,16), Tanh(), Linear(16,16))")
+        return fn
 
     def _make_prenet(self, linear):
         if not linear:
@@ -388,7 +486,26 @@ class VideoGenerator(nn.Module):
         r = super()._apply(fn, *a, **k)
         if hasattr(self, "_pool"):
             self._pool.clear()   # parameter storage may have moved
+            self.__dict__.pop("_labels", None)
+            self.__dict__.pop("_latent_plans", None)
         return r
+
+    def invalidate_packs(self):
+        """Call after writing conv weights behind autograd's back (`p.data.copy_()`, `p.data.clamp_()`,
+        `dist.broadcast(p.data)`): such writes bump neither torch's version counter nor FusedAdam's, so the packed
+        weight panels would stay stale.  In-place ops on the parameter itself, optimiser steps, load_state_dict and
+        .to()/.cuda() are tracked automatically."""
+        for k in [k for k in self._pool.pack_cache if k[0] == "ver"]:
+            del self._pool.pack_cache[k]
+
+    def _zero_labels(self, n, device):
+        """np.zeros(B) -> torch.from_numpy -> .cuda() of the reference (models/mocogan.py:235,279): float64 zeros,
+        never written by anyone, so one cached tensor per batch size serves every call (no fill kernel per call)."""
+        key = (n, device)
+        t = self.__dict__.setdefault("_labels", {}).get(key)
+        if t is None:
+            t = self._labels[key] = torch.zeros(n, dtype=torch.float64, device=device)
+        return t
 
     _gode_direct_grads = True      # the backward kernels can write into a trainer-owned GradArena
 
@@ -420,14 +537,16 @@ class VideoGenerator(nn.Module):
         h = self._run(num_samples, T, False, x, content, None)            # [B*T, 1, H, W, C]
         H, W = h.size(2), h.size(3)
         h = h.view(num_samples, T, H, W, self.n_channels).permute(0, 4, 1, 2, 3)
-        labels = torch.zeros(num_samples, dtype=torch.float64, device=h.device)   # np.zeros(B) -> .cuda() in the reference
-        return h, labels
+        return h, self._zero_labels(num_samples, h.device)
 
     def sample_images(self, num_samples):
         """-> (images [B, C, H, W], None); models/mocogan.py:287-295.  The reference integrates B*T*2 trajectories
         and decodes B randomly chosen rows of the B*T*2*T latent rows; the draws are reproduced exactly on the host
-        and only the chosen trajectories are integrated (exact: trajectories are independent and unselected rows
-        receive no gradient)."""
+        and only the chosen trajectories are integrated.  For the fixed-grid rk4 call of the reference this is exact
+        (trajectories are independent and unselected rows receive no gradient).  With ode_method="dopri5" it is a
+        documented deviation: torchdiffeq accepts/rejects steps on an error norm over ALL B*T*2 trajectories, here
+        the norm is taken over the selected ones, so the accepted step sequence differs (both solutions are within
+        rtol 1e-7 of the exact flow; tests/test_gpu_modules.py::test_dopri5_method_against_oracle pins the size)."""
         T = self.video_length
         n_all = num_samples * T * 2
         content, x = self._draw(n_all, T)
@@ -438,9 +557,37 @@ class VideoGenerator(nn.Module):
         return h.view(num_samples, h.size(2), h.size(3), self.n_channels).permute(0, 3, 1, 2), None
 
     def sample_z_content(self, num_samples, video_len=None):
+        """models/mocogan.py:249-257 -> [N*T, 50], the same code on all T rows of a video."""
         T = video_len if video_len is not None else self.video_length
         c = np.repeat(np.random.normal(0, 1, (num_samples, self.dim_z_content)).astype(np.float32), T, axis=0)
         return torch.from_numpy(c).to(self.main[0].weight.device)
+
+    def sample_z_categ(self, num_samples, video_len=None):
+        """models/mocogan.py:231-247 with dim_z_category == 0 (the only case stage 3 uses): (None, np.zeros(N))."""
+        return None, np.zeros(num_samples)
+
+    def sample_z_m(self, num_samples, video_len=None):
+        """models/mocogan_ode.py:133-148 (UCF class :39-54): torch.randn(N, 16) on the CPU generator -> pre-net ->
+        odeint(rk4 on linspace(0, 1, T)) -> transpose(0, 1).reshape(-1, 16): [N*T, 16], row n*T + t.  One launch of the
+        fused kernel (gode_ode_fwd); differentiable (gode_ode_bwd).  sample_videos()/sample_images() do NOT go
+        through here -- they fuse the solve with the content broadcast and the decoder -- this method exists for
+        the reference's public surface."""
+        T = video_len if video_len is not None else self.video_length
+        _require_gpu(self.main[0].weight, type(self).__name__)
+        x = self._draw_motion(num_samples, T)
+        _, ode = self._param_list()
+        return _LatentFn.apply(self, x, num_samples, T, *ode)
+
+    def _draw_motion(self, num_samples, T):
+        return torch.randn(num_samples, self.dim_z_motion)
+
+    def sample_z_video(self, num_samples, video_len=None):
+        """models/mocogan.py:259-269: (cat([content, motion], dim=1) [N*T, 66], np.zeros(N)); RNG order: NumPy normal
+        for the content first, then torch.randn for the motion noise."""
+        z_content = self.sample_z_content(num_samples, video_len)
+        z_category, z_category_labels = self.sample_z_categ(num_samples, video_len)
+        z_motion = self.sample_z_m(num_samples, video_len)
+        return torch.cat([z_content, z_motion], dim=1), z_category_labels
 
     def forward(self, *a, **k):
         raise RuntimeError("use sample_videos()/sample_images() (the reference never calls forward())")
@@ -455,8 +602,7 @@ class VideoGeneratorMNIST(VideoGenerator):
     mnist = True
 
     def _init_ode_parts(self, ode_fn, dim_hidden, linear, dim_z, ngf):
-        hid = dim_hidden if dim_hidden else self.dim_z_motion
-        self.ode_fn = ode_fn(dim=self.dim_z_motion, dim_hidden=hid)
+        self.ode_fn = self._make_ode_fn(ode_fn, dim_hidden)
         self.main = self._make_main(dim_z, ngf, self.n_channels, mnist=True)
         self.linear = self._make_prenet(linear)
 
@@ -466,8 +612,7 @@ class VideoGeneratorMNISTODE(VideoGeneratorMNIST):
 
     def _init_ode_parts(self, ode_fn, dim_hidden, linear, dim_z, ngf):
         super()._init_ode_parts(ode_fn, dim_hidden, linear, dim_z, ngf)
-        hid = dim_hidden if dim_hidden else self.dim_z_motion
-        self.ode_fn = ode_fn(dim=self.dim_z_motion, dim_hidden=hid)   # re-created, as the reference does
+        self.ode_fn = self._make_ode_fn(ode_fn, dim_hidden)   # re-created, as the reference does
         self.linear = self._make_prenet(linear)
 
 
@@ -535,8 +680,7 @@ class VideoGeneratorMNISTODERNN(VideoGeneratorMNIST):
 
     def _init_ode_parts(self, ode_fn, dim_hidden, linear, dim_z, ngf):
         super()._init_ode_parts(ode_fn, dim_hidden, linear, dim_z, ngf)
-        hid = dim_hidden if dim_hidden else self.dim_z_motion
-        self.ode_fn = ode_fn(dim=self.dim_z_motion, dim_hidden=hid)
+        self.ode_fn = self._make_ode_fn(ode_fn, dim_hidden)
         self.linear = self._make_prenet(linear)
 
     def _param_list(self):
@@ -592,6 +736,7 @@ class _DiscFn(torch.autograd.Function):
         out = plan.forward(training, x=x, x_strides=strides)
         plan.busy = keep
         ctx.plan = plan
+        ctx.lease = _Lease(plan)
         ctx.x_shape = x.shape
         ctx.arena = arena
         return out
@@ -599,6 +744,7 @@ class _DiscFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         plan = ctx.plan
+        ctx.lease.check("discriminator")
         need_x = ctx.needs_input_grad[5]
         need_p = any(ctx.needs_input_grad[6:])
         arena = ctx.arena
@@ -625,7 +771,7 @@ class _DiscFn(torch.autograd.Function):
             grads = [None] * (len(ctx.needs_input_grad) - 6)
         gx = None
         if need_x:
-            g = g_in.clone()                               # [N, D, H, W, C] channels-last (plan buffer is reused)
+            g = g_in                                       # [N, D, H, W, C] channels-last, allocated for this call
             gx = g.permute(0, 4, 1, 2, 3) if len(ctx.x_shape) == 5 else g[:, 0].permute(0, 3, 1, 2)
         return (None, None, None, None, None, gx, *grads)
 
@@ -654,6 +800,11 @@ class _DiscBase(nn.Module):
         if hasattr(self, "_pool"):
             self._pool.clear()
         return r
+
+    def invalidate_packs(self):
+        """See VideoGenerator.invalidate_packs."""
+        for k in [k for k in self._pool.pack_cache if k[0] == "ver"]:
+            del self._pool.pack_cache[k]
 
     def forward(self, input):
         _require_gpu(self.main[1].weight, type(self).__name__)

@@ -59,22 +59,51 @@ def freeze_host_gc():
 # ------------------------------------------------------------------------------------------------------------------
 # loss
 # ------------------------------------------------------------------------------------------------------------------
+_UNIT = {}
+
+
+def unit_grad(device):
+    """A cached device scalar 1.0: `loss.backward(gradient=unit_grad(dev))` spares autograd's ones_like fill, and the
+    loss nodes below recognise it (by address) and hand their stored gradients on without multiplying."""
+    t = _UNIT.get(device)
+    if t is None:
+        t = _UNIT[device] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
+def _scaled(grad, gout):
+    if gout.data_ptr() == unit_grad(gout.device).data_ptr():
+        return grad
+    return grad * gout      # a caller-supplied upstream gradient (not the training loop's path)
+
+
 class _BceConstFn(torch.autograd.Function):
+    """sum_k BCEWithLogits(logits_k, target_k) (mean-reduced each) for 1 or 2 logit tensors in one autograd node: the
+    second term accumulates into the same device scalar (gode_bce_logits accumulate=1), so a discriminator loss
+    `bce(real, 1) + bce(fake, 0)` (mnist_moco_ode.py:126-128) needs no elementwise add."""
+
     @staticmethod
-    def forward(ctx, logits, target):
-        x = logits.contiguous()
-        loss = torch.empty((), dtype=torch.float32, device=x.device)
-        grad = torch.empty_like(x)
-        op = L.BceOp(logits=x.data_ptr(), grad=grad.data_ptr(), loss=loss.data_ptr(), n=x.numel(), target=float(target),
-                     gscale=1.0, accumulate=0)
-        L.run_one(op, stream_ptr())
-        ctx.save_for_backward(grad)
+    def forward(ctx, *args):
+        pairs = [(args[i], args[i + 1]) for i in range(0, len(args), 2)]
+        loss = torch.empty((), dtype=torch.float32, device=pairs[0][0].device)
+        grads = []
+        st = stream_ptr()
+        for k, (logits, target) in enumerate(pairs):
+            x = logits.contiguous()
+            grad = torch.empty_like(x)
+            op = L.BceOp(logits=x.data_ptr(), grad=grad.data_ptr(), loss=loss.data_ptr(), n=x.numel(),
+                         target=float(target), gscale=1.0, accumulate=1 if k else 0)
+            L.run_one(op, st)
+            grads.append(grad)
+        ctx.save_for_backward(*grads)
         return loss
 
     @staticmethod
     def backward(ctx, gout):
-        (grad,) = ctx.saved_tensors
-        return grad * gout, None
+        out = []
+        for g in ctx.saved_tensors:
+            out += [_scaled(g, gout), None]
+        return tuple(out)
 
 
 def bce_with_logits_const(logits: torch.Tensor, target: float) -> torch.Tensor:
@@ -82,6 +111,14 @@ def bce_with_logits_const(logits: torch.Tensor, target: float) -> torch.Tensor:
     if not logits.is_cuda:
         raise RuntimeError("bce_with_logits_const runs only on the GPU through libgode.so")
     return _BceConstFn.apply(logits, target)
+
+
+def bce_with_logits_pair(logits_a, target_a: float, logits_b, target_b: float) -> torch.Tensor:
+    """bce_with_logits_const(a, ta) + bce_with_logits_const(b, tb) as one node (same arithmetic: each term is
+    mean-reduced on its own, the two means are added in fp32)."""
+    if not (logits_a.is_cuda and logits_b.is_cuda):
+        raise RuntimeError("bce_with_logits_pair runs only on the GPU through libgode.so")
+    return _BceConstFn.apply(logits_a, target_a, logits_b, target_b)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -155,8 +192,9 @@ class FusedAdam(torch.optim.Optimizer):
                 if ent["ev"] is None:
                     ent["ev"] = torch.cuda.Event()
                 ent["ev"].record()
-                L.check(lib.gode_adam_multi(ent["dev"].data_ptr(), n, max_n, group["lr"], b1, b2, group["eps"],
-                                            group["weight_decay"], gscale, step, stream_ptr()), "gode_adam_multi")
+                L.call("adam_multi", lambda: L.check(
+                    lib.gode_adam_multi(ent["dev"].data_ptr(), n, max_n, group["lr"], b1, b2, group["eps"],
+                                        group["weight_decay"], gscale, step, stream_ptr()), "gode_adam_multi"))
                 self._keep = keep
         return None
 
@@ -256,18 +294,34 @@ def build_ucf(ngf=64, ndf=64):
         PatchImageDiscriminator(3, ndf=ndf)
 
 
+def _shards(x):
+    return list(x) if isinstance(x, (list, tuple)) else [x]
+
+
 class GanTrainer:
-    """Owns the three networks and their optimisers; step() is one outer iteration of the reference loop."""
+    """Owns the three networks and their optimisers; step() is one outer iteration of the reference loop.
+
+    Data parallelism: with an initialised process group every rank runs the whole iteration on its own
+    shard with per-replica BatchNorm statistics and ONE all-reduce (sum) of each network's flat gradient arena per
+    optimiser step; 1/world is folded into the Adam kernel.  Construction broadcasts rank 0's parameters and buffers so
+    that replicas start (and, with identical updates, stay) equal.  The same semantics are available on ONE GPU as
+    *virtual replicas*: pass a list of shard tensors instead of a tensor and every optimiser step accumulates the
+    shards' gradients in the arena (each shard its own forward/backward, own BatchNorm statistics) and applies
+    1/(world * shards) -- which is how BASELINE configs[2] (batch 256 = 8 x 32) is parity-tested on one device."""
 
     def __init__(self, gen, dis_vid, dis_img, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5, d_iters=2,
-                 process_group=None, freeze_d_in_g_step=True, freeze_gc=True, direct_grads=True):
+                 process_group=None, freeze_d_in_g_step=True, freeze_gc=False, direct_grads=True, sync_replicas=True):
         self.gen, self.dis_vid, self.dis_img = gen, dis_vid, dis_img
         mk = lambda m: FusedAdam(m.parameters(), lr=lr, betas=betas, weight_decay=weight_decay)  # noqa: E731
         self.gen_opt, self.vid_opt, self.img_opt = mk(gen), mk(dis_vid), mk(dis_img)
         self.d_iters, self.group = d_iters, process_group
         self.freeze_d = freeze_d_in_g_step
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if self.world > 1 and sync_replicas:
+            self.broadcast_state()
         self.buckets = {id(m): GradBucket(list(m.parameters())) for m in (gen, dis_vid, dis_img)}
+        # freeze_gc: call freeze_host_gc() after the second iteration (process-global, hence opt-in; bench.py and
+        # long training loops want it, see its docstring)
         self._iters, self._freeze_gc = 0, freeze_gc
         # direct_grads: backward kernels write into a per-network GradArena (see its docstring); networks without
         # the hook (the ODE-RNN generator) and CPU tensors keep the stock autograd accumulation
@@ -282,6 +336,15 @@ class GanTrainer:
                     self.arenas[id(m)] = arena
                     m._gode_arena = arena
 
+    def broadcast_state(self, src=0):
+        """Every replica takes rank `src`'s parameters and buffers (BatchNorm running statistics included)."""
+        for m in (self.gen, self.dis_vid, self.dis_img):
+            with torch.no_grad():
+                for t in list(m.parameters()) + list(m.buffers()):
+                    dist.broadcast(t.detach(), src=src, group=self.group)
+            if hasattr(m, "invalidate_packs"):
+                m.invalidate_packs()
+
     def _begin(self, model, opt):
         a = self.arenas.get(id(model))
         if a is not None:
@@ -289,47 +352,65 @@ class GanTrainer:
         else:
             opt.zero_grad()
 
-    def _opt_step(self, model, opt):
+    def _opt_step(self, model, opt, nshards=1):
         a = self.arenas.get(id(model))
+        gscale = 1.0 / (self.world * nshards)
         if a is not None:
             a.end()
             if self.world > 1:       # the arena is the bucket: one collective, no packing copies
                 dist.all_reduce(a.flat, op=dist.ReduceOp.SUM, group=self.group)
-            opt.step(gscale=1.0 / self.world)
+            opt.step(gscale=gscale)
             return
         if self.world > 1:
             b = self.buckets[id(model)]
             b.gather()
             b.all_reduce(self.group)
-            opt.step(grads=b.views(), gscale=1.0 / self.world)
+            opt.step(grads=b.views(), gscale=gscale)
         else:
-            opt.step()
+            opt.step(gscale=gscale)
+
+    @staticmethod
+    def _mean(losses):
+        if len(losses) == 1:
+            return losses[0]
+        return torch.stack(losses).mean()
 
     def d_image_step(self, real_img):
-        B = real_img.shape[0]
+        """mnist_moco_ode.py:115-131.  real_img: [B,C,H,W], or a list of such shards (virtual replicas)."""
+        shards = _shards(real_img)
         self._begin(self.dis_img, self.img_opt)
-        pr, _ = self.dis_img(real_img)
-        with torch.no_grad():
-            fake, _ = self.gen.sample_images(B)
-        pf, _ = self.dis_img(fake)
-        loss = bce_with_logits_const(pr, 1.0) + bce_with_logits_const(pf, 0.0)
-        loss.backward()
-        self._opt_step(self.dis_img, self.img_opt)
-        return loss.detach()
+        losses = []
+        for x in shards:
+            B = x.shape[0]
+            pr, _ = self.dis_img(x)
+            with torch.no_grad():
+                fake, _ = self.gen.sample_images(B)
+            pf, _ = self.dis_img(fake)
+            loss = bce_with_logits_pair(pr, 1.0, pf, 0.0)
+            loss.backward(gradient=unit_grad(loss.device))
+            losses.append(loss.detach())
+        self._opt_step(self.dis_img, self.img_opt, len(shards))
+        return self._mean(losses)
 
     def d_video_step(self, real_vid):
-        B = real_vid.shape[0]
+        """mnist_moco_ode.py:133-150.  real_vid: [B,T,C,H,W], or a list of such shards."""
+        shards = _shards(real_vid)
         self._begin(self.dis_vid, self.vid_opt)
-        pr, _ = self.dis_vid(real_vid.transpose(1, 2))          # [B,T,C,H,W] -> [B,C,T,H,W] view, read in place
-        with torch.no_grad():
-            fake, _ = self.gen.sample_videos(B)
-        pf, _ = self.dis_vid(fake)
-        loss = bce_with_logits_const(pr, 1.0) + bce_with_logits_const(pf, 0.0)
-        loss.backward()
-        self._opt_step(self.dis_vid, self.vid_opt)
-        return loss.detach()
+        losses = []
+        for x in shards:
+            B = x.shape[0]
+            pr, _ = self.dis_vid(x.transpose(1, 2))             # [B,T,C,H,W] -> [B,C,T,H,W] view, read in place
+            with torch.no_grad():
+                fake, _ = self.gen.sample_videos(B)
+            pf, _ = self.dis_vid(fake)
+            loss = bce_with_logits_pair(pr, 1.0, pf, 0.0)
+            loss.backward(gradient=unit_grad(loss.device))
+            losses.append(loss.detach())
+        self._opt_step(self.dis_vid, self.vid_opt, len(shards))
+        return self._mean(losses)
 
-    def g_step(self, B):
+    def g_step(self, B, shards=1):
+        """mnist_moco_ode.py:153-163; `shards` virtual replicas of batch B each."""
         self._begin(self.gen, self.gen_opt)
         frozen = []
         if self.freeze_d:
@@ -340,28 +421,33 @@ class GanTrainer:
                     if p.requires_grad:
                         p.requires_grad_(False)
                         frozen.append(p)
+        losses = []
         try:
-            fake_vid, _ = self.gen.sample_videos(B)
-            fake_img, _ = self.gen.sample_images(B)
-            pv, _ = self.dis_vid(fake_vid)
-            pi, _ = self.dis_img(fake_img)
-            loss = bce_with_logits_const(pv, 1.0) + bce_with_logits_const(pi, 1.0)
-            loss.backward()
+            for _ in range(shards):
+                fake_vid, _ = self.gen.sample_videos(B)
+                fake_img, _ = self.gen.sample_images(B)
+                pv, _ = self.dis_vid(fake_vid)
+                pi, _ = self.dis_img(fake_img)
+                loss = bce_with_logits_pair(pv, 1.0, pi, 1.0)
+                loss.backward(gradient=unit_grad(loss.device))
+                losses.append(loss.detach())
         finally:
             for p in frozen:
                 p.requires_grad_(True)
-        self._opt_step(self.gen, self.gen_opt)
-        return loss.detach()
+        self._opt_step(self.gen, self.gen_opt, shards)
+        return self._mean(losses)
 
-    def step(self, real_imgs: Sequence[torch.Tensor], real_vids: Sequence[torch.Tensor]):
-        """real_imgs[i]: [B,C,H,W], real_vids[i]: [B,T,C,H,W] for i < d_iters.  Returns the three losses of the last
-        inner pass as device scalars (the reference prints them every 100 iterations)."""
-        B = real_imgs[0].shape[0]
+    def step(self, real_imgs: Sequence, real_vids: Sequence):
+        """real_imgs[i]: [B,C,H,W], real_vids[i]: [B,T,C,H,W] for i < d_iters (each may instead be a LIST of shard
+        tensors: virtual replicas, see the class docstring).  Returns the three losses of the last inner pass as
+        device scalars (the reference prints them every 100 iterations); with shards, their mean over the shards."""
+        first = _shards(real_imgs[0])
+        B, nsh = first[0].shape[0], len(first)
         li = lv = None
         for i in range(self.d_iters):
             li = self.d_image_step(real_imgs[i])
             lv = self.d_video_step(real_vids[i])
-        lg = self.g_step(B)
+        lg = self.g_step(B, nsh)
         self._iters += 1
         if self._freeze_gc and self._iters == 2:     # every plan and program exists now
             freeze_host_gc()

@@ -122,11 +122,15 @@ int gode_bn_apply(const gode_bn_apply_op* op, void* stream);
  *   g_y = gamma*invstd*(g_z - dbeta/M - xhat*dgamma/M)     written in place over g_a.
  * With mean==NULL the layer has no BN: g_y = g_a*act'(y).  work: >= gode_bn_bwd_work_size floats, 8-byte aligned
  * (the two sums are accumulated in fp64).
- * accumulate!=0 adds into dgamma/dbeta. */
+ * accumulate!=0 adds into dgamma/dbeta.
+ * eval_mode!=0: the forward normalised with the RUNNING statistics (mean/invstd hold them), which are constants:
+ *   g_y = gamma*invstd*g_z  (dgamma/dbeta as above, with xhat from the running statistics). */
 typedef struct gode_bn_bwd_op {
   float* g; const float* y; int64_t M; int32_t C, act;
   const float* gamma; const float* mean; const float* invstd; const float* scale; const float* shift;
-  float* dgamma; float* dbeta; float* work; int32_t accumulate, pad_;
+  float* dgamma; float* dbeta; float* work; int32_t accumulate, eval_mode;
+  const float* gin; /* nullable: read g_a from here instead of g (g is then write-only); lets the caller's upstream
+                       gradient tensor be consumed in place without being modified */
 } gode_bn_bwd_op;
 int gode_bn_bwd(const gode_bn_bwd_op* op, void* stream);
 int64_t gode_bn_bwd_work_size(int64_t M, int32_t C);

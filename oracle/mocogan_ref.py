@@ -230,6 +230,65 @@ def train_step(gen, dis_vid, dis_img, opts, real_imgs, real_vids, d_iters=2):
     return li.detach(), lv.detach(), lg.detach()
 
 
+def train_step_dp(gen, dis_vid, dis_img, opts, real_img_shards, real_vid_shards, d_iters=2):
+    """The data-parallel golden of SURVEY 8(e): S replicas, each running the reference's forward/backward on its own
+    shard with its OWN BatchNorm batch statistics, gradients AVERAGED over the replicas before every optimiser step
+    (what one all-reduce(sum)/S per step computes).  real_img_shards[i][s] / real_vid_shards[i][s]: shard s of inner
+    pass i.  The replicas are evaluated one after the other on ONE set of weights (they are identical in DP), drawing
+    their noise from the global generators in shard order; .grad accumulates over the shards (autograd adds) and is
+    divided by S.  Returns the three losses of the last inner pass averaged over shards.  (BatchNorm running statistics
+    see S updates per step here, a replica sees one: they do not enter train-mode arithmetic.)"""
+    gen_opt, vid_opt, img_opt = opts
+    bce = nn.BCEWithLogitsLoss()
+    S = len(real_img_shards[0])
+    batch = real_img_shards[0][0].shape[0]
+
+    def averaged(opt, model, shard_losses):
+        opt.zero_grad()
+        tot = 0.0
+        for fn in shard_losses:
+            loss = fn()
+            loss.backward()
+            tot = tot + loss.detach()
+        for p in model.parameters():
+            if p.grad is not None:
+                p.grad.div_(S)
+        opt.step()
+        return tot / S
+
+    def img_loss(x):
+        def fn():
+            pr, _ = dis_img(x)
+            with torch.no_grad():
+                fake, _ = gen.sample_images(batch)
+            pf, _ = dis_img(fake)
+            return bce(pr, torch.ones_like(pr)) + bce(pf, torch.zeros_like(pf))
+        return fn
+
+    def vid_loss(x):
+        def fn():
+            pr, _ = dis_vid(x.transpose(1, 2))
+            with torch.no_grad():
+                fake, _ = gen.sample_videos(batch)
+            pf, _ = dis_vid(fake)
+            return bce(pr, torch.ones_like(pr)) + bce(pf, torch.zeros_like(pf))
+        return fn
+
+    def gen_loss():
+        fake_vid, _ = gen.sample_videos(batch)
+        fake_img, _ = gen.sample_images(batch)
+        pv, _ = dis_vid(fake_vid)
+        pi, _ = dis_img(fake_img)
+        return bce(pv, torch.ones_like(pv)) + bce(pi, torch.ones_like(pi))
+
+    for i in range(d_iters):
+        li = averaged(img_opt, dis_img, [img_loss(x) for x in real_img_shards[i]])
+        lv = averaged(vid_opt, dis_vid, [vid_loss(x) for x in real_vid_shards[i]])
+    # (the generator step's backward also fills the discriminators' .grad; the next zero_grad discards it)
+    lg = averaged(gen_opt, gen, [gen_loss] * S)
+    return li, lv, lg
+
+
 def build_mnist(ngf=64, ndf=64):
     """mnist_moco_ode.py:75-78."""
     return (Generator(1, 50, 0, 16, 16, ngf=ngf, mnist=True), VideoDisc(1, ksize=2, ndf=ndf),

@@ -13,6 +13,10 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the GPU box shows 256 CPUs but grants a 16-CPU quota: an oversized intra-op pool gets the process throttled
+    # (gan_ode_amd.limit_host_threads docstring); explicit here because importing the package no longer does it
+    import gan_ode_amd
+    gan_ode_amd.limit_host_threads()
 
 
 def pytest_collection_modifyitems(config, items):

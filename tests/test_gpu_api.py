@@ -1,0 +1,183 @@
+"""GPU: the rest of the reference's public surface and the robustness rules of the drop-in modules --
+sample_z_m / sample_z_video (models/mocogan.py:217-269, models/mocogan_ode.py:133-148), eval-mode backward,
+plan leases (a late backward raises instead of reading recycled buffers), the device-resident Rot-MNIST feeder."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, load_sd, rel_err, seed_all
+
+import gan_ode_amd as G
+from oracle import mocogan_ref as M
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _pair(mnist=True, ngf=8):
+    if mnist:
+        gen = G.VideoGeneratorMNISTODE(1, 50, 0, 16, 16, ngf=ngf)
+        ref = M.Generator(1, 50, 0, 16, 16, ngf=ngf, mnist=True)
+    else:
+        gen = G.VideoGenerator(3, 50, 0, 16, 16, dim_hidden=16, ngf=ngf)
+        ref = M.Generator(3, 50, 0, 16, 16, dim_hidden=16, ngf=ngf, mnist=False)
+    ref.load_state_dict(gen.state_dict())
+    return gen.cuda(), ref
+
+
+@pytest.mark.parametrize("mnist", [True, False])
+def test_sample_z_m_and_sample_z_video_against_oracle(mnist):
+    seed_all(3)
+    gen, ref = _pair(mnist)
+    seed_all(4)
+    zm = gen.sample_z_m(5)
+    seed_all(4)
+    rzm = ref.sample_z_m(5)
+    assert zm.shape == (5 * 16, 16) and zm.is_cuda
+    assert rel_err(zm.detach().cpu(), rzm.detach()) < TOL
+    # row n*T + t: frame 0 of every video is the pre-net output itself (Appendix A of SURVEY.md)
+    w = torch.randn(zm.shape, generator=torch.Generator().manual_seed(1))
+    (zm * w.cuda()).sum().backward()
+    (rzm * w).sum().backward()
+    for k in ("ode_fn.fn.0.weight", "ode_fn.fn.0.bias", "ode_fn.fn.2.weight", "ode_fn.fn.2.bias",
+              "linear.0.weight", "linear.0.bias", "linear.2.weight", "linear.2.bias"):
+        a, b = dict(gen.named_parameters())[k].grad, dict(ref.named_parameters())[k].grad
+        assert rel_err(a.cpu(), b) < 2e-4, k
+    # video_len argument and the RNG order of sample_z_video (NumPy content first, then torch.randn)
+    seed_all(6)
+    z, labels = gen.sample_z_video(3, 8)
+    seed_all(6)
+    rz, rlabels = ref.sample_z_video(3, 8)
+    assert z.shape == (24, 66) and isinstance(labels, np.ndarray) and np.array_equal(labels, rlabels)
+    assert torch.equal(z[:, :50].cpu(), rz[:, :50])
+    assert rel_err(z[:, 50:].detach().cpu(), rz[:, 50:].detach()) < TOL
+    assert gen.sample_z_categ(4)[0] is None
+    # decoding those rows with the reference's own call sequence gives sample_videos' frames
+    seed_all(7)
+    vid, _ = gen.sample_videos(3, 8)
+    seed_all(7)
+    rvid, _ = ref.sample_videos(3, 8)
+    assert rel_err(vid.detach().cpu(), rvid.detach()) < TOL
+
+
+def test_sample_videos_labels_are_float64_zeros_and_cached():
+    seed_all(1)
+    gen, _ = _pair()
+    with torch.no_grad():
+        _, l1 = gen.sample_videos(4)
+        _, l2 = gen.sample_videos(4)
+    assert l1.dtype == torch.float64 and l1.shape == (4,) and float(l1.abs().sum()) == 0.0
+    assert l1.data_ptr() == l2.data_ptr()
+
+
+def test_eval_mode_backward_uses_running_statistics():
+    """Advisor finding r1: an eval-mode forward normalises with the running statistics, which are constants -- its
+    backward must not subtract the batch-mean terms.  Generator and both discriminators against the oracle in eval
+    mode (input gradients and parameter gradients)."""
+    g = golden("train_mnist_tiny.npz")
+    gen, dv, di = G.build_mnist(ngf=8, ndf=8)
+    ogen, odv, odi = M.build_mnist(ngf=8, ndf=8)
+    for m, o, p in ((gen, ogen, "gen"), (dv, odv, "vid"), (di, odi, "img")):
+        load_sd(m, g, f"w1/{p}")               # trained one step: running statistics differ from (0, 1)
+        o.load_state_dict({k: v.cpu().clone() for k, v in m.state_dict().items()})
+        m.cuda().eval(); o.eval()
+    seed_all(9)
+    vid, _ = gen.sample_videos(3)
+    pv, _ = dv(vid)
+    x = torch.rand(3, 1, 28, 28, generator=torch.Generator().manual_seed(2))
+    xg = x.cuda().requires_grad_(True)
+    pi, _ = di(xg)
+    (G.bce_with_logits_const(pv, 1.0) + G.bce_with_logits_const(pi, 0.0)).backward()
+    seed_all(9)
+    rvid, _ = ogen.sample_videos(3)
+    rpv, _ = odv(rvid)
+    xr = x.clone().requires_grad_(True)
+    rpi, _ = odi(xr)
+    bce = torch.nn.BCEWithLogitsLoss()
+    (bce(rpv, torch.ones_like(rpv)) + bce(rpi, torch.zeros_like(rpi))).backward()
+    assert rel_err(vid.detach().cpu(), rvid.detach()) < TOL and rel_err(pv.detach().cpu(), rpv.detach()) < TOL
+    assert rel_err(xg.grad.cpu(), xr.grad) < 5e-4
+    for m, o in ((gen, ogen), (dv, odv), (di, odi)):
+        for (k, p), (_, q) in zip(m.named_parameters(), o.named_parameters()):
+            if q.grad is None:
+                assert p.grad is None, k
+            else:
+                assert rel_err(p.grad.cpu(), q.grad) < 2e-3, (k, rel_err(p.grad.cpu(), q.grad))
+    # running statistics untouched by eval-mode passes
+    for (k, v), (_, w) in zip(gen.state_dict().items(), ogen.state_dict().items()):
+        if "running_" in k or "num_batches" in k:
+            assert torch.equal(v.cpu(), w), k
+
+
+def test_late_backward_on_a_recycled_plan_raises_and_dropped_losses_release_plans():
+    seed_all(5)
+    dis = G.PatchImageDiscriminator(1, ndf=8).cuda()
+    x = torch.rand(2, 1, 28, 28).cuda()
+    first, _ = dis(x)
+    kept = [dis(x)[0] for _ in range(G.modules._Pool.MAX_PLANS)]     # all plans of this shape checked out, oldest reused
+    with pytest.raises(RuntimeError, match="reused by a later forward"):
+        first.sum().backward()
+    kept[-1].sum().backward()                                          # the newest forwards are intact
+    # a forward whose loss is dropped gives its plan back when the graph dies: no growth beyond one plan
+    dis2 = G.PatchImageDiscriminator(1, ndf=8).cuda()
+    for _ in range(10):
+        out, _ = dis2(x)
+        del out
+    assert len(dis2._pool.plans[tuple(x.shape)]) == 1
+    # second backward through a retained graph after the plan was reused
+    out, _ = dis2(x)
+    out.sum().backward(retain_graph=True)
+    dis2(x)
+    with pytest.raises(RuntimeError, match="reused by a later forward"):
+        out.sum().backward()
+
+
+def test_rejected_constructor_arguments():
+    with pytest.raises(NotImplementedError, match="dim_hidden"):
+        G.VideoGeneratorMNISTODE(1, 50, 0, 16, 16, dim_hidden=32)
+    with pytest.raises(NotImplementedError, match="dim_hidden"):
+        G.VideoGenerator(3, 50, 0, 16, 16, dim_hidden=8)
+    with pytest.raises(NotImplementedError, match="ode_fn"):
+        G.VideoGeneratorMNISTODE(1, 50, 0, 16, 16, ode_fn=lambda dim, dim_hidden: torch.nn.Linear(dim, dim))
+
+
+def test_invalidate_packs_after_a_write_behind_autograds_back():
+    seed_all(2)
+    dis = G.PatchImageDiscriminator(1, ndf=8).cuda()
+    x = torch.rand(2, 1, 28, 28).cuda()
+    with torch.no_grad():
+        a, _ = dis(x)
+        dis.main[1].weight.data.mul_(2.0)              # .data write: no version bump -> packed panels are stale
+        dis.invalidate_packs()
+        b, _ = dis(x)
+        ref = M.PatchImageDisc(1, ndf=8)
+        ref.load_state_dict({k: v.cpu() for k, v in dis.state_dict().items()})
+        want, _ = ref(x.cpu())
+    assert rel_err(b.cpu(), want) < TOL and rel_err(a.cpu(), want) > 1e-2
+
+
+def test_device_resident_rot_mnist_feeds_the_trainer_bit_identically():
+    """SURVEY 8(f) rank 3 on the device: RotMnistOnDevice(device='cuda') batches (gathered on the GPU, read in place
+    through strides by the first Conv3d) drive GanTrainer.step exactly like the same batches uploaded from host
+    tensors: identical losses and weights, bit for bit."""
+    from gan_ode_amd.data import RotMnistOnDevice
+    X = torch.rand(40, 16, 1, 28, 28, generator=torch.Generator().manual_seed(0))
+    runs = []
+    for device in ("cuda", "cpu"):
+        seed_all(13)
+        gen, dv, di = G.build_mnist(ngf=8, ndf=8)
+        gen.cuda(); dv.cuda(); di.cuda()
+        tr = G.GanTrainer(gen, dv, di)
+        feed = RotMnistOnDevice(X, device=device, seed=7)
+        vs, ims = feed.videos(8), feed.images(8)
+        losses = []
+        for it in range(2):
+            imgs = [next(ims) for _ in range(2)]
+            vids = [next(vs) for _ in range(2)]
+            assert all(t.device.type == device for t in imgs + vids)
+            seed_all(100 + it)
+            losses.append([float(v) for v in tr.step([t.cuda() for t in imgs], [t.cuda() for t in vids])])
+        runs.append((losses, [p.detach().clone() for m in (gen, dv, di) for p in m.parameters()]))
+    assert runs[0][0] == runs[1][0]
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b)

@@ -1,0 +1,132 @@
+"""GPU: data-parallel semantics -- per-replica BatchNorm statistics, gradients averaged over the replicas
+by ONE reduction per optimiser step, 1/world folded into Adam -- against the oracle's golden "S independent shard
+passes with averaged gradients" (oracle.mocogan_ref.train_step_dp).
+
+On one GPU the replicas are *virtual*: GanTrainer takes lists of shard tensors and accumulates the shards' gradients
+in its gradient arena (the buffer RCCL reduces in a real multi-GPU run), which exercises exactly the arithmetic a
+world of S ranks performs (sum of S shard gradients, scaled by 1/S inside the Adam kernel).  The real multi-process
+path is rehearsed with two rank processes sharing the one GPU over gloo (RCCL refuses two ranks on one device);
+hardware scaling numbers come from the driver's 8-GPU run."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, golden, load_sd, seed_all
+
+import gan_ode_amd as G
+from oracle import mocogan_ref as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _f32(a):
+    return torch.from_numpy(np.asarray(a).astype(np.float32))
+
+
+def _check_weights(models, oracles, frac_tol=2e-3):
+    """Post-Adam weights: every entry moved by ~lr * sign-like m/sqrt(v); a wrong gradient shows as ~50 % of the
+    entries off by 2*lr = 4e-4.  Entries whose gradient is within fp32 rounding of zero may flip legitimately."""
+    for m, o in zip(models, oracles):
+        for (k, v), (_, w) in zip(m.state_dict().items(), o.state_dict().items()):
+            if v.dtype == torch.int64 or "running_" in k:
+                continue
+            d = (v.cpu() - w).abs()
+            assert float((d > 6e-5).float().mean()) < frac_tol, (k, float(d.max()), float((d > 6e-5).float().mean()))
+            assert float(d.median()) < 2e-6, (k, float(d.median()))
+
+
+@pytest.mark.parametrize("width,B,S", [(8, 4, 2), (64, 16, 2)])
+def test_virtual_replicas_match_oracle_averaged_shard_gradients(width, B, S):
+    """Two shards of B through the arena (second shard accumulating, 1/2 folded into Adam) against two independent
+    oracle passes with averaged gradients, tiny width and BASELINE width (2 x 16 = one batch of 32 split over two
+    replicas): losses 1e-4 relative, updated weights as in the train-step fixtures."""
+    seed_all(11)
+    gen, dv, di = G.build_mnist(ngf=width, ndf=width)
+    ogen, odv, odi = M.build_mnist(ngf=width, ndf=width)
+    for m, o in zip((gen, dv, di), (ogen, odv, odi)):
+        o.load_state_dict(m.state_dict())
+    gen.cuda(); dv.cuda(); di.cuda()
+    tr = G.GanTrainer(gen, dv, di)
+    opts = M.make_optimizers(ogen, odv, odi)
+    rng = torch.Generator().manual_seed(3)
+    imgs = [[torch.rand(B, 1, 28, 28, generator=rng) for _ in range(S)] for _ in range(2)]
+    vids = [[torch.rand(B, 16, 1, 28, 28, generator=rng) for _ in range(S)] for _ in range(2)]
+    seed_all(12)
+    got = [float(v) for v in tr.step([[x.cuda() for x in sh] for sh in imgs], [[x.cuda() for x in sh] for sh in vids])]
+    seed_all(12)
+    want = [float(v) for v in M.train_step_dp(ogen, odv, odi, opts, imgs, vids)]
+    assert np.allclose(got, want, rtol=1e-4, atol=0), (got, want)
+    _check_weights((gen, dv, di), (ogen, odv, odi))
+    # and it is NOT the single-replica update on the concatenated batch (per-replica BatchNorm statistics differ)
+    seed_all(11)
+    ogen2, odv2, odi2 = M.build_mnist(ngf=width, ndf=width)
+    opts2 = M.make_optimizers(ogen2, odv2, odi2)
+    seed_all(12)
+    one = [float(v) for v in M.train_step(ogen2, odv2, odi2, opts2, [torch.cat(sh) for sh in imgs],
+                                          [torch.cat(sh) for sh in vids])]
+    assert not np.allclose(one, want, rtol=1e-4, atol=0)
+
+
+def test_config2_batch256_as_8_virtual_replicas_of_32():
+    """BASELINE.json configs[2] -- global batch 256 = 8 replicas x 32 clips, ngf=ndf=64 -- one full training iteration
+    with the 8 replicas run back to back on the one GPU, against the oracle's 8 shard passes with averaged
+    gradients.  Losses 1e-4; weights as above."""
+    S, B = 8, 32
+    seed_all(21)
+    gen, dv, di = G.build_mnist()
+    ogen, odv, odi = M.build_mnist()
+    for m, o in zip((gen, dv, di), (ogen, odv, odi)):
+        o.load_state_dict(m.state_dict())
+    gen.cuda(); dv.cuda(); di.cuda()
+    tr = G.GanTrainer(gen, dv, di)
+    opts = M.make_optimizers(ogen, odv, odi)
+    rng = torch.Generator().manual_seed(4)
+    imgs = [[torch.rand(B, 1, 28, 28, generator=rng) for _ in range(S)] for _ in range(2)]
+    vids = [[torch.rand(B, 16, 1, 28, 28, generator=rng) for _ in range(S)] for _ in range(2)]
+    seed_all(22)
+    got = [float(v) for v in tr.step([[x.cuda() for x in sh] for sh in imgs], [[x.cuda() for x in sh] for sh in vids])]
+    seed_all(22)
+    want = [float(v) for v in M.train_step_dp(ogen, odv, odi, opts, imgs, vids)]
+    assert np.allclose(got, want, rtol=1e-4, atol=0), (got, want)
+    _check_weights((gen, dv, di), (ogen, odv, odi))
+
+
+def test_two_rank_processes_on_one_gpu_through_the_bench_launcher():
+    """`python bench.py --gpus 2` as the driver calls it, self-launching (parent spawns the ranks before any GPU call),
+    here with --backend gloo because both ranks share the box's single GPU.  Checks the contract fields and that the
+    replicas stayed in step (the trainer broadcasts rank 0's state; identical all-reduced gradients keep them equal)."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "5",
+                        "--warmup", "2", "--train-steps", "2"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["global_batch"] == 64 and rec["config"]["parallelism"] == "dp2"
+    assert rec["scaling"] == "weak" and rec["value"] > 0 and rec["iteration_ms"] > 0
+    ar = rec["allreduce"]
+    assert ar["collectives_per_iteration"] == 5
+    assert ar["bytes_per_iteration_per_rank"] == 2 * (ar["bucket_bytes"]["dis_img"] + ar["bucket_bytes"]["dis_vid"]) + ar["bucket_bytes"]["gen"]
+    assert rec["cpu_baseline"] is None          # rank-0-at-N=1 only
+
+
+def test_single_gpu_bench_line_through_the_spawn_path():
+    """--gpus 1 --spawn: the same launcher with one rank prints the same kind of line as the in-process run."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--spawn", "--steps", "5", "--warmup", "2",
+                        "--train-steps", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][0])
+    assert rec["n_gpus"] == 1 and rec["roofline"]["bound"] == "mfma" and rec["iteration"]["algorithmic_gflop"] > 100
+    assert rec["allreduce"]["bytes_per_iteration_per_rank"] == 0
+
+
