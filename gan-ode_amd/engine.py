@@ -272,13 +272,15 @@ class ConvStack:
             first.src = x.data_ptr()
             for i in range(5):
                 first.gs[i] = int(x_strides[i])
-            self._x_user, self._x_strides = x, tuple(int(v) for v in x_strides)
+            # aliases WITHOUT autograd history: the plan must not keep the caller's graph (or, below, its own autograd
+            # node, which holds the plan's lease) alive
+            self._x_user, self._x_strides = x.detach(), tuple(int(v) for v in x_strides)
         st = stream_ptr()
         self._run_stale_packs(patch["packs"], st)
         if pre_ops_program is not None:
             pre_ops_program.run(st)
         prog.run(st)
-        self.out = out
+        self.out = out.detach()      # `out` itself becomes the autograd node's output: holding it would be a cycle
         self.generation += 1
         self._fwd_training = training
         return out
