@@ -147,7 +147,9 @@ def test_invalidate_packs_after_a_write_behind_autograds_back():
     x = torch.rand(2, 1, 28, 28).cuda()
     with torch.no_grad():
         a, _ = dis(x)
-        dis.main[1].weight.data.mul_(2.0)              # .data write: no version bump -> packed panels are stale
+        # .data write: no version bump -> packed panels are stale.  (An additive change: the stack is invariant to a
+        # positive rescaling of this layer -- LeakyReLU is homogeneous and the next layer is batch-normalised.)
+        dis.main[1].weight.data.add_(0.05)
         dis.invalidate_packs()
         b, _ = dis(x)
         ref = M.PatchImageDisc(1, ndf=8)
