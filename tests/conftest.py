@@ -51,3 +51,14 @@ def rel_err(a, b):
     a = torch.as_tensor(np.asarray(a), dtype=torch.float64).flatten()
     b = torch.as_tensor(np.asarray(b), dtype=torch.float64).flatten()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def assert_weights_after_adam(v, w, key, frac=5e-3, min_count=4):
+    """Post-Adam weights vs the oracle's: after 1-2 steps every entry has moved by ~lr = 2e-4 times a sign-like
+    m/sqrt(v), so a wrong gradient shows as ~50 % of the entries off by 2*lr.  Entries whose gradient is within fp32
+    rounding noise of zero may flip sign between two correct fp32 evaluations: a small share (and, for short
+    vectors such as BatchNorm gamma, a handful of entries) is allowed."""
+    d = (v.detach().cpu() - torch.as_tensor(w)).abs()
+    flipped = int((d > 6e-5).sum())
+    assert flipped <= max(min_count, frac * d.numel()), (key, flipped, d.numel(), float(d.max()))
+    assert float(d.median()) < 2e-6, (key, float(d.median()))

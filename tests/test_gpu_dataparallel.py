@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import REPO, golden, load_sd, seed_all
+from conftest import REPO, assert_weights_after_adam, seed_all
 
 import gan_ode_amd as G
 from oracle import mocogan_ref as M
@@ -29,15 +29,11 @@ def _f32(a):
 
 
 def _check_weights(models, oracles, frac_tol=2e-3):
-    """Post-Adam weights: every entry moved by ~lr * sign-like m/sqrt(v); a wrong gradient shows as ~50 % of the
-    entries off by 2*lr = 4e-4.  Entries whose gradient is within fp32 rounding of zero may flip legitimately."""
     for m, o in zip(models, oracles):
         for (k, v), (_, w) in zip(m.state_dict().items(), o.state_dict().items()):
             if v.dtype == torch.int64 or "running_" in k:
                 continue
-            d = (v.cpu() - w).abs()
-            assert float((d > 6e-5).float().mean()) < frac_tol, (k, float(d.max()), float((d > 6e-5).float().mean()))
-            assert float(d.median()) < 2e-6, (k, float(d.median()))
+            assert_weights_after_adam(v, w, k, frac=frac_tol)
 
 
 @pytest.mark.parametrize("width,B,S", [(8, 4, 2), (64, 16, 2)])

@@ -90,6 +90,12 @@ CASES = [
     (3, 64, (1, 64, 64), (1, 4, 4), (1, 2, 2), (0, 1, 1), 5),      # UCF generator head at full width (DGRAD, 3 columns, 4 phases x 4 taps): streaming kernel
     (64, 3, (1, 32, 32), (1, 4, 4), (1, 2, 2), (0, 1, 1), 20),     # few-column FPROP with 16 taps (K = 1024) through the same kernel
     (1, 32, (6, 28, 28), (2, 2, 2), (1, 2, 2), (0, 1, 1), 4),      # video-D layer-0 input gradient shape (DGRAD, 1 column, 8 lanes per position)
+    # BASELINE configs[3]: the four k=4 Conv3d layers of the UCF video discriminator at full width AND batch 16
+    (3, 64, (16, 64, 64), (4, 4, 4), (1, 2, 2), (0, 1, 1), 16),
+    (64, 128, (13, 32, 32), (4, 4, 4), (1, 2, 2), (0, 1, 1), 16),
+    (128, 256, (10, 16, 16), (4, 4, 4), (1, 2, 2), (0, 1, 1), 16),
+    (256, 512, (7, 8, 8), (4, 4, 4), (1, 2, 2), (0, 1, 1), 16),
+    (512, 1, (4, 4, 4), (4, 4, 4), (1, 1, 1), (0, 0, 0), 16),
 ]
 
 
