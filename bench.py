@@ -198,6 +198,7 @@ def _parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--train-steps", type=int, default=10, help="iterations for the G/D step timings")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="skip the HIP-graph replay timing of the training iteration")
     ap.add_argument("--spawn", action="store_true",
                     help="go through the rank launcher even for --gpus 1 (N > 1 always does unless a launcher already "
                          "set WORLD_SIZE)")
@@ -308,6 +309,13 @@ def _rank_main(a):
     d_ms = _timed(lambda: (tr.d_image_step(imgs[0]), tr.d_video_step(vids[0])), k, wtr, distributed) / k * 1e3
     g_ms = _timed(lambda: tr.g_step(B), k, wtr, distributed) / k * 1e3
     it_ms = _timed(lambda: tr.step(imgs, vids), k, wtr, distributed, after_warmup=G.freeze_host_gc) / k * 1e3
+    # the same iteration replayed from a HIP graph (single process only): the host then only draws the noise, uploads
+    # it and launches the graph (GanTrainer(graph=True)); bit-identical results (tests/test_gpu_api.py)
+    it_graph_ms = None
+    if not distributed and a.config != "odernn" and not a.no_graph:
+        trg = G.GanTrainer(gen, dv, di, graph=True)
+        trg.gen_opt, trg.vid_opt, trg.img_opt = tr.gen_opt, tr.vid_opt, tr.img_opt     # continue the same optimiser state
+        it_graph_ms = _timed(lambda: trg.step(imgs, vids), k, max(3, wtr), distributed) / k * 1e3
 
     def sample():
         with torch.no_grad():
@@ -337,7 +345,7 @@ def _rank_main(a):
         dist.barrier()       # every rank leaves the collective phase before rank 0 goes off to its single-rank legs
     if rank == 0:
         roof = _kernel_roofline(gen) if a.config == "mnist" else None
-        it_roof = _iteration_roofline(tr, imgs, vids, it_ms) if not distributed else None
+        it_roof = _iteration_roofline(tr, imgs, vids, min(it_ms, it_graph_ms) if it_graph_ms else it_ms) if not distributed else None
         cpu = None if a.no_cpu_baseline or distributed or a.config != "mnist" else _cpu_baseline(threads=G.host_cpu_quota())
         workload = {"mnist": "Rotated-MNIST MoCoGAN+ODE, gen.sample_videos(32): batch 32/GPU, 16x1x28x28, ngf=ndf=64, "
                              "rk4 (Kutta 3/8) on linspace(0,1,16) = 15 steps as the reference code does, train-mode BN, "
@@ -367,8 +375,11 @@ def _rank_main(a):
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}"},
             "global_batch": world * B,
             "step_ms_spread": spread,
-            "d_step_ms": round(d_ms, 3), "g_step_ms": round(g_ms, 3), "iteration_ms": round(it_ms, 3),
-            "train_videos_per_s": round(world * B / (it_ms / 1e3), 2),
+            "d_step_ms": round(d_ms, 3), "g_step_ms": round(g_ms, 3),
+            "iteration_ms": round(min(it_ms, it_graph_ms) if it_graph_ms else it_ms, 3),
+            "iteration_ms_eager": round(it_ms, 3),
+            "iteration_ms_graph": None if it_graph_ms is None else round(it_graph_ms, 3),
+            "train_videos_per_s": round(world * B / ((min(it_ms, it_graph_ms) if it_graph_ms else it_ms) / 1e3), 2),
             "allreduce": allreduce,
             "roofline": roof, "iteration": it_roof, "cpu_baseline": cpu,
         }

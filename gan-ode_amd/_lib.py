@@ -122,7 +122,7 @@ EXPORTS = ["gode_igemm", "gode_igemm_stats_rows", "gode_igemm_work_size", "gode_
            "gode_wgrad_work_size", "gode_wgrad_auto_splits", "gode_bn_finalize", "gode_bn_bwd",
            "gode_bn_bwd_work_size", "gode_bn_apply", "gode_ode_fwd", "gode_ode_bwd", "gode_ode_bwd_work_size", "gode_odernn_fwd",
            "gode_odernn_bwd", "gode_odernn_bwd_work_size", "gode_bce_logits",
-           "gode_adam_l2", "gode_adam_multi", "gode_scale", "gode_run", "gode_version", "gode_sizeof"]
+           "gode_adam_l2", "gode_adam_multi", "gode_adam_multi_dev", "gode_scale", "gode_run", "gode_version", "gode_sizeof"]
 
 _lib = None
 
@@ -164,6 +164,7 @@ def lib():
     L.gode_odernn_bwd_work_size.restype = i64
     L.gode_scale.argtypes = [ptr, ptr, i64, f32, C.c_int, ptr]
     L.gode_adam_multi.argtypes = [ptr, i32, i64, f32, f32, f32, f32, f32, f32, i32, ptr]
+    L.gode_adam_multi_dev.argtypes = [ptr, i32, i64, f32, f32, f32, f32, f32, ptr, ptr]
     L.gode_run.argtypes = [ptr, ptr, i32, ptr]
     _lib = L
     return L

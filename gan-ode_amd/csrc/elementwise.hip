@@ -317,6 +317,33 @@ extern "C" int gode_adam_multi(const gode_adam_tensor* table, int32_t count, int
   return 0;
 }
 
+// The same update with the two step-dependent coefficients read from DEVICE memory (coef[0] = lr / (1 - beta1^step),
+// coef[1] = sqrt(1 - beta2^step), written by the host in the arithmetic of gode_adam_multi): a launch recorded in a
+// HIP graph stays valid while the step count advances -- the host refreshes coef before each replay.
+__global__ void __launch_bounds__(256) adam_multi_dev_kernel(const gode_adam_tensor* table, float b1, float b2, float eps,
+                                                             float wd, float gscale, const float* coef) {
+  const gode_adam_tensor t = table[blockIdx.y];
+  const float step_size = coef[0], bc2_sqrt = coef[1];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < t.n; i += (int64_t)gridDim.x * 256) {
+    const float pi = t.p[i];
+    const float gi = t.g[i] * gscale + wd * pi;
+    const float mi = t.m[i] + (gi - t.m[i]) * (1.f - b1);
+    const float vi = t.v[i] * b2 + (1.f - b2) * gi * gi;
+    t.m[i] = mi; t.v[i] = vi;
+    t.p[i] = pi - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+}
+
+extern "C" int gode_adam_multi_dev(const gode_adam_tensor* table, int32_t count, int64_t max_n, float beta1, float beta2,
+                                   float eps, float weight_decay, float gscale, const float* coef, void* stream) {
+  if (!table || count <= 0 || max_n <= 0 || !coef) return GODE_E_ARG;
+  int bx = (int)((max_n + 255) / 256); if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(adam_multi_dev_kernel, dim3(bx, count), dim3(256), 0, (hipStream_t)stream, table, beta1, beta2, eps,
+                     weight_decay, gscale, coef);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ void __launch_bounds__(256) scale_kernel(float* out, const float* a, int64_t n, float alpha, int acc) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     out[i] = acc ? out[i] + a[i] * alpha : a[i] * alpha;

@@ -240,21 +240,35 @@ class _GenPlan:
 
     def forward(self, x_host, content_host, sel_host, training, keep):
         self._programs()
-        slot = self._ring[self._ring_i]
-        self._ring_i = (self._ring_i + 1) % len(self._ring)
-        if slot["ev"] is not None:
-            slot["ev"].synchronize()
-        slot["x"].copy_(x_host)
-        slot["c"].copy_(content_host)
-        if self.select:
-            slot["s"].copy_(sel_host)
-        self._in.copy_(slot["buf"], non_blocking=True)
-        if slot["ev"] is None:
-            slot["ev"] = torch.cuda.Event()
-        slot["ev"].record()
+        feed = getattr(self.gen, "_feed", None)
+        if feed is not None and feed.recording:
+            # graph capture (GanTrainer(graph=True)): the inputs travel in the trainer's HostFeed block; the recorded
+            # copy is device -> device from the block's static region for this call site
+            nfl = self._in.numel()
+            pin, dev = feed.noise_region(self.gen, self.select, self.n, self.T, nfl)
+            self._pack_inputs(pin, x_host, content_host, sel_host)
+            self._in.copy_(dev)
+        else:
+            slot = self._ring[self._ring_i]
+            self._ring_i = (self._ring_i + 1) % len(self._ring)
+            if slot["ev"] is not None:
+                slot["ev"].synchronize()
+            self._pack_inputs(slot["buf"], x_host, content_host, sel_host)
+            self._in.copy_(slot["buf"], non_blocking=True)
+            if slot["ev"] is None:
+                slot["ev"] = torch.cuda.Event()
+            slot["ev"].record()
         out = self.stack.forward(training, pre_ops_program=self.fwd_prog)
         self.busy = keep
         return out
+
+    def _pack_inputs(self, buf, x_host, content_host, sel_host):
+        """[x | content 50 per trajectory | sel (int32 bits) 1 per trajectory] -- the layout of self._in."""
+        nx, n = x_host.numel(), self.n
+        buf[:nx].copy_(x_host.reshape(-1))
+        buf[nx:nx + n * 50].copy_(content_host.reshape(-1))
+        if self.select:
+            buf[nx + n * 50:nx + n * 51].view(torch.int32).copy_(sel_host)
 
     def backward(self, gout, arena=None):
         if arena is not None:
@@ -530,10 +544,39 @@ class VideoGenerator(nn.Module):
         return _GenFn.apply(plan, x, content, sel, self.training, keep, len(dec), *dec, *ode)
 
     # -- reference API ---------------------------------------------------------------------------------------------
+    def _host_inputs(self, select, num_samples, T):
+        """The host-drawn inputs of one sample_videos (select False) / sample_images (select True) call, consuming the
+        NumPy and torch CPU generators exactly as the reference does: -> (x [n_traj, 16], content [n_traj, 50],
+        sel int32 [n_traj] or None).  sample_images: the reference integrates B*T*2 trajectories and decodes B randomly
+        chosen rows of the B*T*2*T latent rows (models/mocogan.py:287-295); all draws are made, only the chosen
+        trajectories are kept."""
+        if not select:
+            content, x = self._draw(num_samples, T)
+            return x, content, None
+        n_all = num_samples * T * 2
+        content, x = self._draw(n_all, T)
+        j = np.sort(np.random.choice(n_all * T, num_samples, replace=False)).astype(np.int64)
+        traj = torch.from_numpy(j // T)
+        sel = torch.from_numpy((j % T).astype(np.int32))
+        return self._take_trajectories(x, traj), content[traj].contiguous(), sel
+
+    @staticmethod
+    def _take_trajectories(x, traj):
+        return x[traj].contiguous()
+
+    def _fill_host_inputs(self, buf, select, num_samples, T):
+        """Graph replay (HostFeed): the same draws, written straight into the feed block's region for this call site."""
+        x, content, sel = self._host_inputs(select, num_samples, T)
+        nx, n = x.numel(), content.shape[0]
+        buf[:nx].copy_(x.reshape(-1))
+        buf[nx:nx + n * 50].copy_(content.reshape(-1))
+        if select:
+            buf[nx + n * 50:nx + n * 51].view(torch.int32).copy_(sel)
+
     def sample_videos(self, num_samples, video_len=None):
         """-> (videos [B, C, T, H, W] fp32, float64 zero labels [B]); models/mocogan.py:271-285."""
         T = video_len if video_len is not None else self.video_length
-        content, x = self._draw(num_samples, T)
+        x, content, _ = self._host_inputs(False, num_samples, T)
         h = self._run(num_samples, T, False, x, content, None)            # [B*T, 1, H, W, C]
         H, W = h.size(2), h.size(3)
         h = h.view(num_samples, T, H, W, self.n_channels).permute(0, 4, 1, 2, 3)
@@ -548,12 +591,8 @@ class VideoGenerator(nn.Module):
         the norm is taken over the selected ones, so the accepted step sequence differs (both solutions are within
         rtol 1e-7 of the exact flow; tests/test_gpu_modules.py::test_dopri5_method_against_oracle pins the size)."""
         T = self.video_length
-        n_all = num_samples * T * 2
-        content, x = self._draw(n_all, T)
-        j = np.sort(np.random.choice(n_all * T, num_samples, replace=False)).astype(np.int64)
-        traj = torch.from_numpy(j // T)
-        sel = torch.from_numpy((j % T).astype(np.int32))
-        h = self._run(num_samples, T, True, x[traj].contiguous(), content[traj].contiguous(), sel)
+        x, content, sel = self._host_inputs(True, num_samples, T)
+        h = self._run(num_samples, T, True, x, content, sel)
         return h.view(num_samples, h.size(2), h.size(3), self.n_channels).permute(0, 3, 1, 2), None
 
     def sample_z_content(self, num_samples, video_len=None):
@@ -703,15 +742,13 @@ class VideoGeneratorMNISTODERNN(VideoGeneratorMNIST):
             buf[i].normal_()
         return torch.from_numpy(content), buf
 
-    def sample_images(self, num_samples):
-        T = self.video_length
-        n_all = num_samples * T * 2
-        content, noise = self._draw(n_all, T)
-        j = np.sort(np.random.choice(n_all * T, num_samples, replace=False)).astype(np.int64)
-        traj = torch.from_numpy(j // T)
-        sel = torch.from_numpy((j % T).astype(np.int32))
-        h = self._run(num_samples, T, True, noise[:, traj].contiguous(), content[traj].contiguous(), sel)
-        return h.view(num_samples, h.size(2), h.size(3), self.n_channels).permute(0, 3, 1, 2), None
+    @staticmethod
+    def _take_trajectories(noise, traj):
+        return noise[:, traj].contiguous()        # noise stack [T+1, n, 16]: trajectories are the middle axis
+
+    def sample_z_m(self, num_samples, video_len=None):
+        raise NotImplementedError("VideoGeneratorMNISTODERNN.sample_z_m: the ODE-RNN latent is produced inside "
+                                  "sample_videos()/sample_images() (gode_odernn_fwd); it is not exposed on its own")
 
 
 # ==================================================================================================================

@@ -7,6 +7,7 @@ the d_iters=2 structure below follow that body line by line.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import List, Optional, Sequence
 
 import torch
@@ -136,15 +137,25 @@ class FusedAdam(torch.optim.Optimizer):
                                       maximize=False, foreach=None, capturable=False, differentiable=False,
                                       fused=None, decoupled_weight_decay=False))
 
+    @staticmethod
+    def step_coefficients(lr, beta1, beta2, step):
+        """(lr / (1 - beta1^step), sqrt(1 - beta2^step)) in gode_adam_multi's arithmetic: the hyper-parameters pass
+        through C floats, the bias corrections are evaluated in double and rounded to float."""
+        import numpy as np
+        lr, b1, b2 = float(np.float32(lr)), float(np.float32(beta1)), float(np.float32(beta2))
+        return (float(np.float32(lr / (1.0 - b1 ** float(step)))), float(np.float32((1.0 - b2 ** float(step)) ** 0.5)))
+
     @torch.no_grad()
-    def step(self, closure=None, grads: Optional[dict] = None, gscale: float = 1.0):
+    def step(self, closure=None, grads: Optional[dict] = None, gscale: float = 1.0, feed=None):
         """grads: optional {param: tensor} overriding .grad (views into an all-reduced bucket); gscale multiplies
         every gradient (1/world_size for data parallelism).  All tensors of a param group are updated by ONE launch
-        (gode_adam_multi) driven by a small device table of pointers."""
+        (gode_adam_multi) driven by a small device table of pointers, uploaded only when a pointer changed.
+        feed: a HostFeed (graph capture): the step-dependent coefficients are then read from the feed's device block
+        (gode_adam_multi_dev), so the recorded launch stays valid while the step count advances."""
         assert closure is None
         import numpy as np
         lib = L.lib()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
             rows, keep, step, max_n, dev = [], [], None, 0, None
             for p in group["params"]:
@@ -165,6 +176,8 @@ class FusedAdam(torch.optim.Optimizer):
                 if step is None:
                     step = s_now
                 if s_now != step:       # parameters on different step counts: fall back to one launch each
+                    if feed is not None:
+                        raise RuntimeError("graph capture needs all parameters of a group on the same Adam step")
                     L.run_one(L.AdamOp(p=p.data_ptr(), g=g.data_ptr(), m=st["exp_avg"].data_ptr(),
                                        v=st["exp_avg_sq"].data_ptr(), n=p.numel(), lr=group["lr"], beta1=b1, beta2=b2,
                                        eps=group["eps"], weight_decay=group["weight_decay"], gscale=gscale,
@@ -182,21 +195,122 @@ class FusedAdam(torch.optim.Optimizer):
                     tbl = self._tables = {}
                 n = len(rows)
                 ent = tbl.get(id(group))
-                if ent is None or ent["host"].shape[0] < n:
-                    ent = tbl[id(group)] = dict(host=torch.empty((n, 5), dtype=torch.int64).pin_memory(),
-                                                dev=torch.empty((n, 5), dtype=torch.int64, device=dev), ev=None)
-                if ent["ev"] is not None:
-                    ent["ev"].synchronize()
-                ent["host"][:n].copy_(torch.from_numpy(np.asarray(rows, dtype=np.int64)))
-                ent["dev"][:n].copy_(ent["host"][:n], non_blocking=True)
-                if ent["ev"] is None:
-                    ent["ev"] = torch.cuda.Event()
-                ent["ev"].record()
-                L.call("adam_multi", lambda: L.check(
-                    lib.gode_adam_multi(ent["dev"].data_ptr(), n, max_n, group["lr"], b1, b2, group["eps"],
-                                        group["weight_decay"], gscale, step, stream_ptr()), "gode_adam_multi"))
+                key = tuple(rows)
+                if ent is None or ent.get("key") != key:
+                    # (the pointers of parameters, arena gradients and moments do not change from step to step: the
+                    # table is uploaded once, not per step)
+                    if feed is not None:
+                        raise RuntimeError("graph capture: the Adam pointer table must exist already (run eager "
+                                           "iterations first)")
+                    if ent is None or ent["host"].shape[0] != n:
+                        ent = tbl[id(group)] = dict(host=torch.empty((n, 5), dtype=torch.int64).pin_memory(),
+                                                    dev=torch.empty((n, 5), dtype=torch.int64, device=dev), ev=None)
+                    if ent["ev"] is not None:
+                        ent["ev"].synchronize()          # the previous upload from this pinned buffer has completed
+                    ent["key"] = key
+                    ent["host"].copy_(torch.from_numpy(np.asarray(rows, dtype=np.int64)))
+                    ent["dev"].copy_(ent["host"], non_blocking=True)
+                    if ent["ev"] is None:
+                        ent["ev"] = torch.cuda.Event()
+                    ent["ev"].record()
+                if feed is not None:
+                    coef = feed.adam_slot(self, gi, group["lr"], b1, b2, step)
+                    L.call("adam_multi", lambda: L.check(
+                        lib.gode_adam_multi_dev(ent["dev"].data_ptr(), n, max_n, b1, b2, group["eps"],
+                                                group["weight_decay"], gscale, coef, stream_ptr()), "gode_adam_multi_dev"))
+                else:
+                    L.call("adam_multi", lambda: L.check(
+                        lib.gode_adam_multi(ent["dev"].data_ptr(), n, max_n, group["lr"], b1, b2, group["eps"],
+                                            group["weight_decay"], gscale, step, stream_ptr()), "gode_adam_multi"))
                 self._keep = keep
         return None
+
+    def advance_steps(self, group_index=0):
+        """Host-side bookkeeping of one optimiser step that a replayed graph performed on the device: the `step`
+        entries of the state (checkpoints, the next coefficient upload) move on by one."""
+        for p in self.param_groups[group_index]["params"]:
+            st = self.state.get(p)
+            if st:
+                st["step"] += 1
+
+    def current_step(self, group_index=0):
+        for p in self.param_groups[group_index]["params"]:
+            st = self.state.get(p)
+            if st:
+                return int(st["step"].item())
+        return 0
+
+
+class HostFeed:
+    """Everything the host contributes to one training iteration besides the launch itself -- the latent noise drawn
+    from the NumPy / torch CPU generators (the reference's RNG contract) and Adam's step-dependent coefficients -- laid
+    out in ONE pinned block that is uploaded with ONE copy into a static device block read by the captured graph.
+    During capture the block's layout is recorded as a script (in program order); before every replay the script is
+    walked again: same draws in the same order, coefficients for the new step counts."""
+
+    FLOATS = 1 << 18
+
+    def __init__(self, device):
+        self.device = device
+        self.dev = torch.zeros(self.FLOATS, dtype=torch.float32, device=device)
+        self.pinned = [torch.zeros(self.FLOATS, dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.events = [None, None]
+        self.parity = 0
+        self.script, self.size = [], 0
+        self.recording = False
+
+    # -- capture ---------------------------------------------------------------------------------------------------
+    def _reserve(self, n):
+        off = self.size
+        self.size = off + ((n + 3) // 4) * 4                 # 16-byte aligned regions
+        if self.size > self.FLOATS:
+            raise RuntimeError("HostFeed block too small")
+        return off
+
+    def noise_region(self, gen, select, num_samples, T, nfloats):
+        """-> (pinned view to fill now, device view the captured copy reads)"""
+        assert self.recording
+        off = self._reserve(nfloats)
+        self.script.append(("noise", gen, select, num_samples, T, off, nfloats))
+        return self.pinned[self.parity][off:off + nfloats], self.dev[off:off + nfloats]
+
+    def adam_slot(self, opt, group_index, lr, b1, b2, step):
+        assert self.recording
+        off = self._reserve(2)
+        self.script.append(("adam", opt, group_index, lr, b1, b2, off))
+        c = FusedAdam.step_coefficients(lr, b1, b2, step)
+        self.pinned[self.parity][off], self.pinned[self.parity][off + 1] = c[0], c[1]
+        return self.dev[off:off + 2].data_ptr()
+
+    # -- replay ----------------------------------------------------------------------------------------------------
+    def begin(self):
+        """Next pinned buffer (waits until the upload that last used it has been consumed)."""
+        self.parity ^= 1
+        ev = self.events[self.parity]
+        if ev is not None:
+            ev.synchronize()
+        return self.pinned[self.parity]
+
+    def fill_from_script(self):
+        buf = self.begin()
+        for ent in self.script:
+            if ent[0] == "noise":
+                _, gen, select, num_samples, T, off, nfloats = ent
+                gen._fill_host_inputs(buf[off:off + nfloats], select, num_samples, T)
+            else:
+                _, opt, gi, lr, b1, b2, off = ent
+                opt.advance_steps(gi)
+                c = FusedAdam.step_coefficients(lr, b1, b2, opt.current_step(gi))
+                buf[off], buf[off + 1] = c[0], c[1]
+
+    def upload(self):
+        """One H2D copy of the used part of the block on the current stream (ordered before the replay that reads it,
+        after the replay that read the previous contents)."""
+        n = self.size
+        self.dev[:n].copy_(self.pinned[self.parity][:n], non_blocking=True)
+        if self.events[self.parity] is None:
+            self.events[self.parity] = torch.cuda.Event()
+        self.events[self.parity].record()
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -310,7 +424,8 @@ class GanTrainer:
     1/(world * shards) -- which is how BASELINE configs[2] (batch 256 = 8 x 32) is parity-tested on one device."""
 
     def __init__(self, gen, dis_vid, dis_img, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5, d_iters=2,
-                 process_group=None, freeze_d_in_g_step=True, freeze_gc=False, direct_grads=True, sync_replicas=True):
+                 process_group=None, freeze_d_in_g_step=True, freeze_gc=False, direct_grads=True, sync_replicas=True,
+                 overlap_image_d=True, graph=False):
         self.gen, self.dis_vid, self.dis_img = gen, dis_vid, dis_img
         mk = lambda m: FusedAdam(m.parameters(), lr=lr, betas=betas, weight_decay=weight_decay)  # noqa: E731
         self.gen_opt, self.vid_opt, self.img_opt = mk(gen), mk(dis_vid), mk(dis_img)
@@ -320,6 +435,27 @@ class GanTrainer:
         if self.world > 1 and sync_replicas:
             self.broadcast_state()
         self.buckets = {id(m): GradBucket(list(m.parameters())) for m in (gen, dis_vid, dis_img)}
+        # overlap_image_d: inside step() the image discriminator's forward/backward/Adam (some 50 latency-bound
+        # launches of 5-30 us each at batch 32) run on a side stream next to the video-discriminator step's big GEMMs.
+        # Everything that touches the generator stays on the caller's stream in program order (its BatchNorm running
+        # statistics are updated by every sample_* call), each stream executes the same kernels in the same order as
+        # the serial schedule, so results are bit-identical to overlap_image_d=False.
+        self._side = None
+        if overlap_image_d and next(dis_img.parameters()).is_cuda:
+            self._side = torch.cuda.Stream(device=next(dis_img.parameters()).device)
+        self._side_pending = False
+        # graph: after two eager iterations (every plan, program and pointer table exists, the pack pattern is the
+        # steady-state one) step() captures ONE whole iteration -- both streams, autograd's backward passes, the five
+        # Adam launches -- in a HIP graph and from then on replays it: per iteration the host draws the latent noise
+        # (same generators, same order: HostFeed), uploads it with one copy and launches the graph.  Measured at
+        # BASELINE configs[1] the eager iteration is within ~25 % of being host-bound (scripts/host_floor.py: 7.5-8.2 ms
+        # of Python + launch calls per iteration against ~11 ms of kernels); the replay needs ~2 ms of host time.
+        # Single-process only (a captured RCCL all-reduce is not attempted); arena gradients required.
+        self._graph_mode = bool(graph)
+        self._graph = None
+        self._feed = None
+        if self._graph_mode and self.world > 1:
+            raise NotImplementedError("GanTrainer(graph=True) is single-process; data-parallel runs use the eager schedule")
         # freeze_gc: call freeze_host_gc() after the second iteration (process-global, hence opt-in; bench.py and
         # long training loops want it, see its docstring)
         self._iters, self._freeze_gc = 0, freeze_gc
@@ -359,7 +495,8 @@ class GanTrainer:
             a.end()
             if self.world > 1:       # the arena is the bucket: one collective, no packing copies
                 dist.all_reduce(a.flat, op=dist.ReduceOp.SUM, group=self.group)
-            opt.step(gscale=gscale)
+            feed = getattr(opt, "_feed", None)
+            opt.step(gscale=gscale, feed=feed if (feed is not None and feed.recording) else None)
             return
         if self.world > 1:
             b = self.buckets[id(model)]
@@ -375,22 +512,46 @@ class GanTrainer:
             return losses[0]
         return torch.stack(losses).mean()
 
-    def d_image_step(self, real_img):
+    def d_image_step(self, real_img, _join=True):
         """mnist_moco_ode.py:115-131.  real_img: [B,C,H,W], or a list of such shards (virtual replicas)."""
         shards = _shards(real_img)
-        self._begin(self.dis_img, self.img_opt)
+        side = self._side
+        main = torch.cuda.current_stream() if side is not None else None
+        if side is not None and not self._side_pending:
+            side.wait_stream(main)          # inputs prepared on the caller's stream; later passes only wait for `fake`
+            self._side_pending = True
+        on_side = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
+        with on_side():
+            self._begin(self.dis_img, self.img_opt)
         losses = []
         for x in shards:
             B = x.shape[0]
-            pr, _ = self.dis_img(x)
+            with on_side():
+                pr, _ = self.dis_img(x)
             with torch.no_grad():
-                fake, _ = self.gen.sample_images(B)
-            pf, _ = self.dis_img(fake)
-            loss = bce_with_logits_pair(pr, 1.0, pf, 0.0)
-            loss.backward(gradient=unit_grad(loss.device))
+                fake, _ = self.gen.sample_images(B)      # generator work stays on the caller's stream
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                fake.record_stream(side)
+            with on_side():
+                pf, _ = self.dis_img(fake)
+                loss = bce_with_logits_pair(pr, 1.0, pf, 0.0)
+                loss.backward(gradient=unit_grad(loss.device))
             losses.append(loss.detach())
-        self._opt_step(self.dis_img, self.img_opt, len(shards))
-        return self._mean(losses)
+        with on_side():
+            self._opt_step(self.dis_img, self.img_opt, len(shards))
+            out = self._mean(losses)
+        if _join:
+            self._join_side()
+        return out
+
+    def _join_side(self):
+        """The caller's stream waits for the image-discriminator work queued on the side stream."""
+        if self._side is not None and self._side_pending:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_pending = False
 
     def d_video_step(self, real_vid):
         """mnist_moco_ode.py:133-150.  real_vid: [B,T,C,H,W], or a list of such shards."""
@@ -440,18 +601,74 @@ class GanTrainer:
     def step(self, real_imgs: Sequence, real_vids: Sequence):
         """real_imgs[i]: [B,C,H,W], real_vids[i]: [B,T,C,H,W] for i < d_iters (each may instead be a LIST of shard
         tensors: virtual replicas, see the class docstring).  Returns the three losses of the last inner pass as
-        device scalars (the reference prints them every 100 iterations); with shards, their mean over the shards."""
+        device scalars (the reference prints them every 100 iterations); with shards, their mean over the shards.
+        In graph mode the returned scalars are static tensors that the next step() overwrites."""
+        if self._graph_mode and self._iters >= 2 and not isinstance(real_imgs[0], (list, tuple)):
+            return self._graph_step(real_imgs, real_vids)
+        return self._eager_step(real_imgs, real_vids)
+
+    def _eager_step(self, real_imgs, real_vids):
         first = _shards(real_imgs[0])
         B, nsh = first[0].shape[0], len(first)
         li = lv = None
         for i in range(self.d_iters):
-            li = self.d_image_step(real_imgs[i])
+            li = self.d_image_step(real_imgs[i], _join=False)     # side stream (see overlap_image_d)
             lv = self.d_video_step(real_vids[i])
+        self._join_side()                                         # the G step reads the updated image discriminator
         lg = self.g_step(B, nsh)
         self._iters += 1
         if self._freeze_gc and self._iters == 2:     # every plan and program exists now
             freeze_host_gc()
         return li, lv, lg
+
+    # -- HIP-graph replay of the iteration ---------------------------------------------------------------------------
+    def _graph_step(self, real_imgs, real_vids):
+        key = (tuple(real_imgs[0].shape), tuple(real_vids[0].shape))
+        if self._graph is not None and self._graph["key"] != key:
+            raise RuntimeError("GanTrainer(graph=True): batch shapes changed after capture "
+                               f"({self._graph['key']} -> {key}); build a new trainer for the new shapes")
+        if self._graph is None:
+            self._capture(real_imgs, real_vids, key)
+        else:
+            g = self._graph
+            for dst, src in zip(g["imgs"] + g["vids"], list(real_imgs) + list(real_vids)):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+            self._feed.fill_from_script()        # host draws + Adam coefficients for this iteration, in program order
+            self._feed.upload()
+            g["graph"].replay()
+        for m in (self.gen, self.dis_vid, self.dis_img):
+            m.invalidate_packs()                 # eager passes after a replay must re-pack (versions did not move)
+        self._iters += 1
+        return self._graph["losses"]
+
+    def _capture(self, real_imgs, real_vids, key):
+        dev = real_imgs[0].device
+        for m in (self.gen, self.dis_vid, self.dis_img):
+            if id(m) not in self.arenas:
+                raise NotImplementedError("GanTrainer(graph=True) needs gradient arenas on all three networks "
+                                          f"({type(m).__name__} has none)")
+        imgs = [t.detach().clone() for t in real_imgs]      # static inputs: later iterations are copied into them
+        vids = [t.detach().clone() for t in real_vids]
+        feed = self._feed = HostFeed(dev)
+        self.gen._feed = feed
+        for o in (self.gen_opt, self.vid_opt, self.img_opt):
+            o._feed = feed
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        feed.begin()
+        feed.recording = True
+        try:
+            with torch.cuda.graph(graph):
+                losses = self._eager_step(imgs, vids)
+        finally:
+            feed.recording = False
+        self._iters -= 1                        # _eager_step counted the capture pass; _graph_step counts it
+        self._graph = dict(key=key, graph=graph, imgs=imgs, vids=vids, losses=losses)
+        # nothing has executed yet: capture only recorded the launches.  The host inputs of THIS iteration were drawn
+        # (and the Adam step counts advanced) while recording; upload them and run the iteration.
+        feed.upload()
+        graph.replay()
 
 
 def train_step(trainer: GanTrainer, real_imgs, real_vids):

@@ -227,6 +227,12 @@ typedef struct gode_adam_tensor { float* p; const float* g; float* m; float* v; 
 int gode_adam_multi(const gode_adam_tensor* table, int32_t count, int64_t max_n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, float gscale, int32_t step, void* stream);
 
+/* gode_adam_multi with the step-dependent coefficients read from device memory: coef[0] = lr / (1 - beta1^step),
+ * coef[1] = sqrt(1 - beta2^step), both evaluated in double and rounded to float exactly as gode_adam_multi does.  A
+ * launch captured in a HIP graph then stays valid across steps (the host rewrites coef before every replay). */
+int gode_adam_multi_dev(const gode_adam_tensor* table, int32_t count, int64_t max_n, float beta1, float beta2, float eps,
+                        float weight_decay, float gscale, const float* coef, void* stream);
+
 /* out[i] = a[i]*alpha (+ out[i] if accumulate); small utility for gradient bucket handling */
 int gode_scale(float* out, const float* a, int64_t n, float alpha, int accumulate, void* stream);
 

@@ -183,3 +183,66 @@ def test_device_resident_rot_mnist_feeds_the_trainer_bit_identically():
     assert runs[0][0] == runs[1][0]
     for a, b in zip(runs[0][1], runs[1][1]):
         assert torch.equal(a, b)
+
+
+def test_image_discriminator_side_stream_is_bitwise_the_serial_schedule():
+    """GanTrainer(overlap_image_d=True) runs the image-discriminator step on a side stream next to the video step; both
+    streams execute the same kernels in the same order, generator work (and with it the BatchNorm running statistics)
+    stays on the caller's stream: losses, weights, running statistics and Adam state are bit-identical."""
+    runs = []
+    for overlap in (True, False):
+        seed_all(23)
+        gen, dv, di = G.build_mnist(ngf=16, ndf=16)
+        gen.cuda(); dv.cuda(); di.cuda()
+        tr = G.GanTrainer(gen, dv, di, overlap_image_d=overlap)
+        assert (tr._side is not None) == overlap
+        rng = torch.Generator().manual_seed(9)
+        losses = []
+        for it in range(3):
+            imgs = [torch.rand(8, 1, 28, 28, generator=rng).cuda() for _ in range(2)]
+            vids = [torch.rand(8, 16, 1, 28, 28, generator=rng).cuda() for _ in range(2)]
+            seed_all(200 + it)
+            losses.append([float(v) for v in tr.step(imgs, vids)])
+        torch.cuda.synchronize()
+        state = [v.detach().clone() for m in (gen, dv, di) for v in m.state_dict().values()]
+        state += [tr.img_opt.state[p]["exp_avg_sq"].clone() for p in di.parameters()]
+        runs.append((losses, state))
+    assert runs[0][0] == runs[1][0]
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b)
+
+
+def test_graph_replayed_iterations_are_bitwise_the_eager_ones():
+    """GanTrainer(graph=True): two eager iterations, then the whole iteration (both streams, the backward passes, five
+    Adam launches) is captured in a HIP graph and replayed; the host still draws the noise from the NumPy / torch CPU
+    generators in the reference's order (HostFeed) and feeds Adam's step-dependent coefficients.  Losses, weights,
+    BatchNorm buffers and optimiser state are bit-identical to the eager schedule over six iterations, eager sampling
+    between replays sees the updated weights, and the checkpointed step counts are right."""
+    runs = []
+    for graph in (True, False):
+        seed_all(31)
+        gen, dv, di = G.build_mnist(ngf=16, ndf=16)
+        gen.cuda(); dv.cuda(); di.cuda()
+        tr = G.GanTrainer(gen, dv, di, graph=graph)
+        rng = torch.Generator().manual_seed(10)
+        losses, samples = [], []
+        for it in range(6):
+            imgs = [torch.rand(8, 1, 28, 28, generator=rng).cuda() for _ in range(2)]
+            vids = [torch.rand(8, 16, 1, 28, 28, generator=rng).cuda() for _ in range(2)]
+            seed_all(300 + it)
+            losses.append([float(v) for v in tr.step(imgs, vids)])
+            if it == 3:                      # eager use of the same modules between two replays
+                seed_all(77)
+                with torch.no_grad():
+                    samples.append(gen.sample_videos(3)[0].clone())
+        torch.cuda.synchronize()
+        assert (tr._graph is not None) == graph
+        state = [v.detach().clone() for m in (gen, dv, di) for v in m.state_dict().values()]
+        state += [tr.gen_opt.state[p]["exp_avg"].clone() for p in gen.parameters() if p in tr.gen_opt.state and tr.gen_opt.state[p]]
+        steps = [int(tr.img_opt.state[next(di.parameters())]["step"]), int(tr.gen_opt.state[gen.main[0].weight]["step"])]
+        runs.append((losses, state, samples, steps))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b)
+    assert torch.equal(runs[0][2][0], runs[1][2][0])
+    assert runs[0][3] == runs[1][3] == [12, 6]
