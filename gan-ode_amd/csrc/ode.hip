@@ -12,6 +12,7 @@
 // operand of the next and the weights are pre-loaded in that k order -- no cross-lane traffic in the whole solve.
 // Only the parameter-gradient outer products of the adjoint pass (sum over trajectories) need a transpose; it goes
 // through a 1.25 KB per-matrix LDS tile and is again an MFMA (k = trajectory).
+#include <stdlib.h>
 #include "common.h"
 
 #include "ode_common.h"
@@ -105,7 +106,17 @@ __global__ void __launch_bounds__(256) ode_fwd_kernel(const gode_ode_fwd_op a) {
 }
 
 int gode_launch_ode_dopri5(const gode_ode_fwd_op* op, hipStream_t st);   // odernn.hip
-
+int gode_launch_ode_fwd_valu(const gode_ode_fwd_op* op, hipStream_t st);  // ode_valu.hip (default mapping)
+int gode_launch_ode_bwd_valu(const gode_ode_bwd_op* op, hipStream_t st);
+// Two mappings of the same arithmetic (different summation order): the VALU/DPP kernels of ode_valu.hip (4 trajectories
+// per wave, short dependent chains: 14 / 33 us forward / adjoint at the config size N = 32 against 21 / 53 us) and the
+// MFMA-chain kernels of this file (16 trajectories per wave: 67 vs 43 TFLOP/s forward at N = 2^20).  Default: VALU up
+// to 8192 trajectories, MFMA above; GODE_ODE_MFMA=1 / =0 forces one (the A/B of profiles/r02_ode_kernels.txt).
+static bool ode_use_mfma(int N) {
+  static const char* e = getenv("GODE_ODE_MFMA");
+  if (e) return atoi(e) != 0;
+  return N > 8192;
+}
 extern "C" int gode_ode_fwd(const gode_ode_fwd_op* op, void* stream) {
   if (op && op->method == 1) {
     if (!op->x || !op->z || !op->tout || op->N <= 0 || op->T < 1 || !(op->rtol > 0.f) || !(op->atol >= 0.f)) return GODE_E_ARG;
@@ -120,6 +131,7 @@ extern "C" int gode_ode_fwd(const gode_ode_fwd_op* op, void* stream) {
   if (op->zcols < 68 || op->zcols % 4 != 0) return GODE_E_ARG;
   if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2) return GODE_E_ARG;
   if (op->prenet && (!op->p.Wa || !op->p.ba || !op->p.Wb || !op->p.bb)) return GODE_E_ARG;
+  if (!ode_use_mfma(op->N)) return gode_launch_ode_fwd_valu(op, (hipStream_t)stream);
   hipLaunchKernelGGL(ode_fwd_kernel, dim3((op->N + 15) / 16), dim3(op->content ? 256 : 64), 0, (hipStream_t)stream, *op);
   GODE_LAUNCH_CHECK();
   return 0;
@@ -275,8 +287,13 @@ extern "C" int gode_ode_bwd(const gode_ode_bwd_op* op, void* stream) {
   if ((op->bstep_off == nullptr) != (op->bstep_dt == nullptr)) return GODE_E_ARG;
   const int nblk = (op->N + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ode_bwd_kernel, dim3(nblk), dim3(64), 0, st, *op);
-  GODE_LAUNCH_CHECK();
+  if (!ode_use_mfma(op->N)) {
+    const int rc = gode_launch_ode_bwd_valu(op, st);
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(ode_bwd_kernel, dim3(nblk), dim3(64), 0, st, *op);
+    GODE_LAUNCH_CHECK();
+  }
   const int first = op->prenet ? 0 : OFF_W1;
   hipLaunchKernelGGL(ode_bwd_reduce_kernel, dim3((GODE_ODE_NPARAM - first + 255) / 256), dim3(256), 0, st, op->work, op->grads,
                      nblk, op->accumulate, first);
