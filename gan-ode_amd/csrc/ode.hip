@@ -292,16 +292,23 @@ __global__ void __launch_bounds__(256) ode_bwd_reduce_chunks_kernel(float* work,
 
 extern "C" int64_t gode_ode_bwd_work_size(int32_t N) { return (int64_t)((N + 15) / 16) * GODE_ODE_NPARAM; }
 
+int gode_launch_ode_dopri5_bwd(const gode_ode_bwd_op* op, hipStream_t st);   // adj_adaptive.hip
+
 extern "C" int gode_ode_bwd(const gode_ode_bwd_op* op, void* stream) {
-  if (!op || !op->traj || !op->gz || !op->dt || !op->work || !op->grads || op->N <= 0 || op->T < 1 || op->substeps < 1)
-    return GODE_E_ARG;
+  const bool adaptive = op && op->method == 1 && op->substeps == 0;
+  if (!op || !op->traj || !op->gz || !op->work || !op->grads || op->N <= 0 || op->T < 1) return GODE_E_ARG;
+  if (adaptive ? (!op->tout || !(op->rtol > 0.f) || !(op->atol >= 0.f)) : (!op->dt || op->substeps < 1)) return GODE_E_ARG;
+  if (op->method != 0 && op->method != 1) return GODE_E_ARG;
   if (op->zcols < 16 || op->zcols % 4 != 0) return GODE_E_ARG;
   if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2) return GODE_E_ARG;
   if (op->prenet && (!op->x || !op->p.Wa || !op->p.ba || !op->p.Wb || !op->p.bb)) return GODE_E_ARG;
   if ((op->bstep_off == nullptr) != (op->bstep_dt == nullptr)) return GODE_E_ARG;
   const int nblk = (op->N + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
-  if (!ode_use_mfma(op->N)) {
+  if (adaptive) {
+    const int rc = gode_launch_ode_dopri5_bwd(op, st);
+    if (rc) return rc;
+  } else if (!ode_use_mfma(op->N)) {
     const int rc = gode_launch_ode_bwd_valu(op, st);
     if (rc) return rc;
   } else {

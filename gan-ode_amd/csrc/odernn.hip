@@ -410,15 +410,23 @@ __global__ void __launch_bounds__(256) odernn_bwd_reduce_kernel(const float* wor
 
 extern "C" int64_t gode_odernn_bwd_work_size(int32_t N) { return (int64_t)((N + 15) / 16) * RNN_NPARAM; }
 
+int gode_launch_odernn_bwd_adaptive(const gode_odernn_bwd_op* op, hipStream_t st);   // adj_adaptive.hip
+
 extern "C" int gode_odernn_bwd(const gode_odernn_bwd_op* op, void* stream) {
-  if (!op || !op->noise || !op->hp || !op->gz || !op->work || !op->grads || op->N <= 0 || op->T < 1 || op->substeps < 1)
+  if (!op || !op->noise || !op->hp || !op->gz || !op->work || !op->grads || op->N <= 0 || op->T < 1 || op->substeps < 0)
     return GODE_E_ARG;
+  if (op->substeps == 0 && (!(op->rtol > 0.f) || !(op->atol >= 0.f))) return GODE_E_ARG;
   if (op->zcols < 16 || op->zcols % 4 != 0) return GODE_E_ARG;
   if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2 || !op->p.Wih || !op->p.Whh || !op->p.bih || !op->p.bhh) return GODE_E_ARG;
   const int nblk = (op->N + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(odernn_bwd_kernel, dim3(nblk), dim3(64), 0, st, *op);
-  GODE_LAUNCH_CHECK();
+  if (op->substeps == 0) {
+    const int rc = gode_launch_odernn_bwd_adaptive(op, st);
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(odernn_bwd_kernel, dim3(nblk), dim3(64), 0, st, *op);
+    GODE_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(odernn_bwd_reduce_kernel, dim3((RNN_NPARAM + 255) / 256), dim3(256), 0, st, op->work, op->grads, nblk,
                      op->accumulate);
   GODE_LAUNCH_CHECK();

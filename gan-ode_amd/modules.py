@@ -218,13 +218,14 @@ class _GenPlan:
                                      T=self.T, substeps=self.gen.ode_substeps, prenet=prenet, accumulate=0, zcols=zcols)
             self._grid = None
             if self.gen.ode_method == "dopri5":
-                # torchdiffeq's adaptive solver over the output times; the adjoint is the same continuous adjoint,
-                # integrated here with `adjoint_substeps` fixed Kutta-3/8 steps per output interval (torchdiffeq
-                # integrates it adaptively to rtol/atol): the deviation recorded for the ODE-RNN generator
+                # torchdiffeq's adaptive solver over the output times; the adjoint call is integrated adaptively too
+                # (adjoint_substeps == 0, gode_ode_bwd method 1) or with `adjoint_substeps` fixed Kutta-3/8 steps
                 self._tout = torch.linspace(0, 1, self.T).float().to(self.device)
                 self._nsteps = torch.zeros((self.n + 63) // 64, dtype=torch.int32, device=self.device)
                 self.fwd_op.method, self.fwd_op.rtol, self.fwd_op.atol = 1, float(self.gen.ode_rtol), float(self.gen.ode_atol)
                 self.fwd_op.tout, self.fwd_op.nsteps = dptr(self._tout), dptr(self._nsteps)
+                self.bwd_op.method, self.bwd_op.rtol, self.bwd_op.atol = 1, float(self.gen.ode_rtol), float(self.gen.ode_atol)
+                self.bwd_op.tout = dptr(self._tout)
             elif self.gen.ode_method != "rk4":
                 raise NotImplementedError(f"ode_method {self.gen.ode_method!r}: libgode implements 'rk4' (the reference's "
                                           "call) and 'dopri5'")
@@ -382,7 +383,9 @@ class VideoGenerator(nn.Module):
     _plan_cls = None   # set below (_GenPlan)
     # the reference passes method='rk4' (models/mocogan_ode.py:50,144); 'dopri5' is what BASELINE configs[3] words
     ode_method = "rk4"
-    ode_rtol, ode_atol, adjoint_substeps = 1e-7, 1e-9, 4
+    # adjoint_substeps (dopri5 only): 0 = the adjoint is integrated adaptively with the same controller and
+    # torchdiffeq's mixed norm, as odeint_adjoint does; k > 0 = k fixed Kutta-3/8 steps per output interval
+    ode_rtol, ode_atol, adjoint_substeps = 1e-7, 1e-9, 0
 
     def __init__(self, n_channels, dim_z_content, dim_z_category, dim_z_motion, video_length, ode_fn=ODEFunc,
                  dim_hidden=None, linear=True, ngf=64):
@@ -685,9 +688,11 @@ class _RnnGenPlan(_GenPlan):
                                         N=self.n, T=self.T, rtol=self.gen.ode_rtol, atol=self.gen.ode_atol, zcols=Z_COLS)
             self.bwd_op = L.OdeRnnBwdOp(p=op, noise=dptr(self.noise), hp=dptr(self.hp), sel_t=dptr(self.sel), gz=None,
                                         work=dptr(self.rnn_work), grads=None, N=self.n, T=self.T,
-                                        substeps=self.gen.adjoint_substeps, accumulate=0, zcols=Z_COLS)
+                                        substeps=self.gen.adjoint_substeps, accumulate=0, zcols=Z_COLS,
+                                        rtol=self.gen.ode_rtol, atol=self.gen.ode_atol)
             self.fwd_prog = L.Program([self.fwd_op])
         self.fwd_op.rtol, self.fwd_op.atol = self.gen.ode_rtol, self.gen.ode_atol
+        self.bwd_op.rtol, self.bwd_op.atol = self.gen.ode_rtol, self.gen.ode_atol
         self.bwd_op.substeps = self.gen.adjoint_substeps
 
     def backward(self, gout):
@@ -715,7 +720,7 @@ class VideoGeneratorMNISTODERNN(VideoGeneratorMNIST):
 
     _plan_cls = _RnnGenPlan
     ode_rtol, ode_atol = 1e-7, 1e-9
-    adjoint_substeps = 32
+    adjoint_substeps = 0      # 0: adaptive adjoint (torchdiffeq's behaviour); 32 was round 1's fixed discretisation
 
     def _init_ode_parts(self, ode_fn, dim_hidden, linear, dim_z, ngf):
         super()._init_ode_parts(ode_fn, dim_hidden, linear, dim_z, ngf)

@@ -176,6 +176,12 @@ typedef struct gode_ode_bwd_op {
    * grid torchdiffeq builds for the reversed span): steps bstep_dt[bstep_off[j-1] .. bstep_off[j]) for j = 1..T-1.
    * NULL: `substeps` equal steps of dt[j-1]/substeps. */
   const int32_t* bstep_off; const float* bstep_dt;
+  /* method 1 with substeps == 0: torchdiffeq's ADAPTIVE adjoint of a dopri5 solve -- the augmented state (y, a, g_theta)
+   * of the one adjoint call is integrated backwards over the output times tout[T] with dopri5 (rtol, atol), mixed norm
+   * (max over the RMS norms of y, a and each ODEFunc parameter tensor, joint over a workgroup's <= 64 trajectories);
+   * the theta state is carried across the output intervals, the solver restarts on each.  method 1 with substeps > 0:
+   * the same adjoint discretised with `substeps` fixed Kutta-3/8 steps per interval (round-1 behaviour; dt required). */
+  int32_t method, pad_; float rtol, atol; const float* tout;
 } gode_ode_bwd_op;
 int gode_ode_bwd(const gode_ode_bwd_op* op, void* stream);
 int64_t gode_ode_bwd_work_size(int32_t N);
@@ -197,13 +203,16 @@ typedef struct gode_odernn_fwd_op {
   int32_t N, T; float rtol, atol; int32_t zcols, pad_;
 } gode_odernn_fwd_op;
 int gode_odernn_fwd(const gode_odernn_fwd_op* op, void* stream);
-/* backward: GRU backward + continuous adjoint of every unit-interval solve, discretised with `substeps` fixed
- * reverse-time Kutta-3/8 steps (torchdiffeq integrates the same adjoint adaptively to 1e-7; 32 substeps agree to
- * ~1e-6).  grads: 2176 floats = W1,b1,W2,b2,Wih,Whh,bih,bhh.  work >= gode_odernn_bwd_work_size floats. */
+/* backward: GRU backward + continuous adjoint of every unit-interval solve.  substeps == 0 (what the Python side
+ * uses): integrated ADAPTIVELY as torchdiffeq does -- per frame one adjoint call, dopri5 (rtol, atol) on the augmented
+ * state (y, a, g_theta), mixed norm joint over a workgroup's <= 64 trajectories.  substeps > 0: `substeps` fixed
+ * reverse-time Kutta-3/8 steps per frame (32 agree with the adaptive result to ~1e-6).
+ * grads: 2176 floats = W1,b1,W2,b2,Wih,Whh,bih,bhh.  work >= gode_odernn_bwd_work_size floats. */
 typedef struct gode_odernn_bwd_op {
   gode_odernn_params p;
   const float* noise; const float* hp; const int32_t* sel_t; const float* gz;
   float* work; float* grads; int32_t N, T, substeps, accumulate, zcols, pad_;
+  float rtol, atol;   /* substeps == 0: adaptive adjoint (dopri5 on (y, a, g_theta) per frame, mixed norm), as torchdiffeq */
 } gode_odernn_bwd_op;
 int gode_odernn_bwd(const gode_odernn_bwd_op* op, void* stream);
 int64_t gode_odernn_bwd_work_size(int32_t N);

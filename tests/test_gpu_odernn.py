@@ -2,7 +2,9 @@
 and the drop-in generator class against the CPU oracle (oracle.mocogan_ref.GeneratorOdeRnn on oracle.ode_ref's
 dopri5).  Parity is unpinned for this row (reference file un-importable, torchdiffeq absent, no fixture).
 Adaptive step sequences differ between two fp32 implementations, so states agree to the solver tolerance (~1e-6),
-asserted at 2e-5; gradients (fixed 32-substep adjoint vs the oracle's adaptive adjoint) at 5e-4."""
+asserted at 2e-5; gradients: the device's ADAPTIVE adjoint (dopri5 on (y, a, g_theta) with torchdiffeq's mixed norm,
+substeps=0, the default) against the oracle's adaptive adjoint at 1e-4 (measured ~1e-6), and the fixed 32-substep
+discretisation kept as an option, also at 1e-4 (measured ~4e-6)."""
 import numpy as np
 import pytest
 import torch
@@ -59,15 +61,17 @@ def test_odernn_kernels_against_oracle(N, T):
     gz.view(N, T, 72)[:, :, :16] = gup.cuda()
     grads = torch.full((L.ODERNN_NPARAM,), float("nan"), device="cuda")
     work = torch.empty(L.lib().gode_odernn_bwd_work_size(N), device="cuda")
-    bop = L.OdeRnnBwdOp(p=op, noise=nz.data_ptr(), hp=hp_d.data_ptr(), sel_t=None, gz=gz.data_ptr(), work=work.data_ptr(),
-                        grads=grads.data_ptr(), N=N, T=T, substeps=32, accumulate=0, zcols=72)
-    L.run_one(bop, stream())
-    g = grads.cpu()
-    off = 0
-    for name, r in zip(("W1", "b1", "W2", "b2", "Wih", "Whh", "bih", "bhh"), ref_grads):
-        n = r.numel()
-        assert rel_err(g[off:off + n].view_as(r), r) < 5e-4, name
-        off += n
+    for substeps, tol in ((0, 1e-4), (32, 1e-4)):       # 0: adaptive adjoint (what torchdiffeq does); 32: fixed Kutta-3/8
+        grads.fill_(float("nan"))
+        bop = L.OdeRnnBwdOp(p=op, noise=nz.data_ptr(), hp=hp_d.data_ptr(), sel_t=None, gz=gz.data_ptr(), work=work.data_ptr(),
+                            grads=grads.data_ptr(), N=N, T=T, substeps=substeps, accumulate=0, zcols=72, rtol=1e-7, atol=1e-9)
+        L.run_one(bop, stream())
+        g = grads.cpu()
+        off = 0
+        for name, r in zip(("W1", "b1", "W2", "b2", "Wih", "Whh", "bih", "bhh"), ref_grads):
+            n = r.numel()
+            assert rel_err(g[off:off + n].view_as(r), r) < tol, (name, substeps, rel_err(g[off:off + n].view_as(r), r))
+            off += n
 
 
 def test_odernn_generator_against_oracle():
