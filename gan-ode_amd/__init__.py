@@ -7,12 +7,12 @@ anything does, and there is no fallback path.
 from . import _lib
 from .modules import (Noise, ODEFunc, PatchImageDiscriminator, VideoDiscriminator, VideoGenerator,
                       VideoGeneratorMNIST, VideoGeneratorMNISTODE, VideoGeneratorMNISTODERNN)
-from .train import (FusedAdam, GanTrainer, bce_with_logits_const, bce_with_logits_pair, build_mnist, build_ucf,
+from .train import (FusedAdam, GanTrainer, bce_with_logits_const, bce_with_logits_halves, bce_with_logits_pair, build_mnist, build_ucf,
                     freeze_host_gc, host_cpu_quota, limit_host_threads, train_step, unit_grad)
 
 __all__ = ["Noise", "ODEFunc", "PatchImageDiscriminator", "VideoDiscriminator", "VideoGenerator",
            "VideoGeneratorMNIST", "VideoGeneratorMNISTODE", "VideoGeneratorMNISTODERNN", "FusedAdam", "GanTrainer", "bce_with_logits_const",
-           "bce_with_logits_pair", "unit_grad", "build_mnist", "build_ucf", "train_step", "host_cpu_quota", "limit_host_threads", "freeze_host_gc", "_lib"]
+           "bce_with_logits_pair", "bce_with_logits_halves", "unit_grad", "build_mnist", "build_ucf", "train_step", "host_cpu_quota", "limit_host_threads", "freeze_host_gc", "_lib"]
 
 # Process-global host tuning is opt-in (nothing happens at import): call limit_host_threads() once at start-up when
 # torch's intra-op pool is larger than the container's CPU quota (see its docstring; bench.py and tests/conftest.py

@@ -29,7 +29,7 @@ class ConvGeom(C.Structure):
 class IgemmOp(C.Structure):
     _fields_ = [("g", ConvGeom), ("dir", i32), ("act", i32), ("epilogue", i32), ("tile", i32), ("src", ptr),
                 ("wpack", ptr), ("out", ptr), ("scale", ptr), ("shift", ptr), ("stats", ptr), ("gs", i64 * 5),
-                ("work", ptr)]
+                ("work", ptr), ("groups", i32), ("pad3_", i32)]
     KIND = OP_IGEMM
 
 
@@ -44,7 +44,7 @@ class BnFinalizeOp(C.Structure):
     _fields_ = [("stats", ptr), ("rows", i32), ("ncols", i32), ("C", i32), ("count", i64), ("gamma", ptr),
                 ("beta", ptr), ("running_mean", ptr), ("running_var", ptr), ("num_batches_tracked", ptr),
                 ("mean", ptr), ("invstd", ptr), ("scale", ptr), ("shift", ptr), ("momentum", f32), ("eps", f32),
-                ("training", i32), ("pad_", i32)]
+                ("training", i32), ("pad_", i32), ("groups", i32), ("rows0", i32)]
     KIND = OP_BN_FINALIZE
 
 
@@ -94,7 +94,8 @@ class OdeRnnBwdOp(C.Structure):
 
 
 class BnApplyOp(C.Structure):
-    _fields_ = [("y", ptr), ("out", ptr), ("scale", ptr), ("shift", ptr), ("M", i64), ("C", i32), ("act", i32)]
+    _fields_ = [("y", ptr), ("out", ptr), ("scale", ptr), ("shift", ptr), ("M", i64), ("C", i32), ("act", i32),
+                ("M0", i64)]
     KIND = OP_BN_APPLY
 
 
@@ -119,7 +120,7 @@ _STRUCTS = {0: ConvGeom, OP_IGEMM: IgemmOp, OP_WGRAD: WgradOp, OP_BN_FINALIZE: B
             OP_ODE_FWD: OdeFwdOp, OP_ODE_BWD: OdeBwdOp, OP_BCE: BceOp, OP_ADAM: AdamOp, OP_PACK: PackOp,
             OP_ODERNN_FWD: OdeRnnFwdOp, OP_ODERNN_BWD: OdeRnnBwdOp, OP_BN_APPLY: BnApplyOp}
 
-EXPORTS = ["gode_igemm", "gode_igemm_stats_rows", "gode_igemm_work_size", "gode_pack_size", "gode_pack_weights", "gode_wgrad",
+EXPORTS = ["gode_igemm", "gode_igemm_stats_rows", "gode_igemm_stats_rows0", "gode_igemm_work_size", "gode_pack_size", "gode_pack_weights", "gode_wgrad",
            "gode_wgrad_work_size", "gode_wgrad_auto_splits", "gode_bn_finalize", "gode_bn_bwd",
            "gode_bn_bwd_work_size", "gode_bn_apply", "gode_ode_fwd", "gode_ode_bwd", "gode_ode_bwd_work_size", "gode_odernn_fwd",
            "gode_odernn_bwd", "gode_odernn_bwd_work_size", "gode_bce_logits",
@@ -149,6 +150,7 @@ def lib():
         getattr(L, name).argtypes = [ptr, ptr]
         getattr(L, name).restype = C.c_int
     L.gode_igemm_stats_rows.argtypes = [ptr]
+    L.gode_igemm_stats_rows0.argtypes = [ptr]
     L.gode_igemm_work_size.argtypes = [ptr]
     L.gode_igemm_work_size.restype = i64
     L.gode_pack_size.argtypes = [ptr, C.c_int]

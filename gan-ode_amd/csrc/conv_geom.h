@@ -32,6 +32,7 @@ struct PhaseGeom {
   int32_t Pd, Ph, Pw;   // output position offsets
   int32_t kd0, kh0, kw0;// first canonical tap per dim (for packing / wgrad)
   int32_t row0;         // first partial-stats row (m-block index) of this phase
+  int32_t img0;         // first image of this phase (0 except for the image groups of a grouped FPROP, see gode_igemm_op.groups)
   int64_t w_off;        // float offset of this phase's panel inside wpack
 };
 
@@ -72,7 +73,7 @@ inline int gode_build_igemm_geom(const gode_conv_geom& g, int dir, IgemmGeom* ou
     p.Md = g.Do; p.Mh = g.Ho; p.Mw = g.Wo; p.M = g.N * p.Md * p.Mh * p.Mw;
     p.Td = g.kd; p.Th = g.kh; p.Tw = g.kw; p.K = p.Td * p.Th * p.Tw * G.Cg; p.Kp = (p.K + 3) & ~3;
     p.Od = -g.pd; p.Oh = -g.ph; p.Ow = -g.pw; p.Pd = p.Ph = p.Pw = 0;
-    p.kd0 = p.kh0 = p.kw0 = 0; p.row0 = 0; p.w_off = 0;
+    p.kd0 = p.kh0 = p.kw0 = 0; p.row0 = 0; p.img0 = 0; p.w_off = 0;
     return 0;
   }
   if (dir != GODE_DGRAD) return GODE_E_ARG;
@@ -84,7 +85,7 @@ inline int gode_build_igemm_geom(const gode_conv_geom& g, int dir, IgemmGeom* ou
     G.kstep_d = G.kstep_h = G.kstep_w = 1;
     PhaseGeom& p = G.ph[0];
     p.Md = p.Mh = p.Mw = 1; p.M = g.N; p.Td = p.Th = p.Tw = 1; p.K = G.Cg; p.Kp = (p.K + 3) & ~3;
-    p.Od = p.Oh = p.Ow = 0; p.Pd = p.Ph = p.Pw = 0; p.kd0 = p.kh0 = p.kw0 = 0; p.row0 = 0; p.w_off = 0;
+    p.Od = p.Oh = p.Ow = 0; p.Pd = p.Ph = p.Pw = 0; p.kd0 = p.kh0 = p.kw0 = 0; p.row0 = 0; p.img0 = 0; p.w_off = 0;
     return 0;
   }
   if (g.sd * g.sh * g.sw > GODE_MAX_PHASES) return GODE_E_SHAPE;
@@ -114,7 +115,7 @@ inline int gode_build_igemm_geom(const gode_conv_geom& g, int dir, IgemmGeom* ou
         p.Td = T[0]; p.Th = T[1]; p.Tw = T[2]; p.K = T[0] * T[1] * T[2] * G.Cg; p.Kp = (p.K + 3) & ~3;
         p.Od = O[0]; p.Oh = O[1]; p.Ow = O[2]; p.Pd = fd; p.Ph = fh; p.Pw = fw;
         p.kd0 = k0[0]; p.kh0 = k0[1]; p.kw0 = k0[2];
-        p.row0 = 0; p.w_off = woff;
+        p.row0 = 0; p.img0 = 0; p.w_off = woff;
         woff += (int64_t)G.Ncols * p.Kp;
       }
   G.nphase = np;

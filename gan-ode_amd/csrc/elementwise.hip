@@ -10,46 +10,59 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const gode_bn_finalize
   const int c = blockIdx.x, tid = threadIdx.x;
   __shared__ double red[2][256];
   if (a.training) {
-    // stats[which][column][row] (column = rep*C + c): consecutive threads read consecutive rows of one column
+    // stats[which][column][row] (column = rep*C + c): consecutive threads read consecutive rows of one column.
+    // groups == 2: rows [0, rows0) are image group 0, [rows0, rows) group 1 -- finalised one after the other, so the
+    // running statistics see the two momentum updates in the order of the reference's two forward calls
     const int reps = a.ncols / a.C;
-    double s1 = 0.0, s2 = 0.0;
-    const int64_t items = (int64_t)a.rows * reps;
-    for (int64_t i = tid; i < items; i += 256) {
-      const int rep = (int)(i / a.rows); const int r = (int)(i - (int64_t)rep * a.rows);
-      const int64_t o = (int64_t)(rep * a.C + c) * a.rows + r;
-      s1 += (double)a.stats[o];
-      s2 += (double)a.stats[(int64_t)a.ncols * a.rows + o];
-    }
-    red[0][tid] = s1; red[1][tid] = s2;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; }
-      __syncthreads();
-    }
-    if (tid == 0) {
-      const double n = (double)a.count;
-      const double mean = red[0][0] / n;
-      double var = red[1][0] / n - mean * mean;
-      if (var < 0.0) var = 0.0;
-      const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
-      const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
-      const float sc = g * invstd;
-      a.mean[c] = (float)mean; a.invstd[c] = invstd;
-      a.scale[c] = sc; a.shift[c] = b - (float)mean * sc;
-      if (a.running_mean) {
-        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
-        a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
-        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+    const int ngroups = a.groups == 2 ? 2 : 1;
+    for (int grp = 0; grp < ngroups; ++grp) {
+      const int r_lo = grp == 0 ? 0 : a.rows0, r_hi = (ngroups == 2 && grp == 0) ? a.rows0 : a.rows;
+      const int nr = r_hi - r_lo;
+      double s1 = 0.0, s2 = 0.0;
+      const int64_t items = (int64_t)nr * reps;
+      for (int64_t i = tid; i < items; i += 256) {
+        const int rep = (int)(i / nr); const int r = r_lo + (int)(i - (int64_t)rep * nr);
+        const int64_t o = (int64_t)(rep * a.C + c) * a.rows + r;
+        s1 += (double)a.stats[o];
+        s2 += (double)a.stats[(int64_t)a.ncols * a.rows + o];
       }
-      if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+      __syncthreads();
+      red[0][tid] = s1; red[1][tid] = s2;
+      __syncthreads();
+      for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; }
+        __syncthreads();
+      }
+      if (tid == 0) {
+        const double n = (double)a.count;
+        const double mean = red[0][0] / n;
+        double var = red[1][0] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
+        const float sc = g * invstd;
+        const int o = grp * a.C + c;
+        a.mean[o] = (float)mean; a.invstd[o] = invstd;
+        a.scale[o] = sc; a.shift[o] = b - (float)mean * sc;
+        if (a.running_mean) {
+          const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+          a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+          a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+        }
+        if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+      }
     }
   } else if (tid == 0) {
     const float invstd = 1.f / sqrtf(a.running_var[c] + a.eps);
     const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
     const float sc = g * invstd;
-    if (a.mean) a.mean[c] = a.running_mean[c];
-    if (a.invstd) a.invstd[c] = invstd;
-    a.scale[c] = sc; a.shift[c] = b - a.running_mean[c] * sc;
+    const int ngroups = a.groups == 2 ? 2 : 1;
+    for (int grp = 0; grp < ngroups; ++grp) {      // eval mode: both groups normalise with the running statistics
+      const int o = grp * a.C + c;
+      if (a.mean) a.mean[o] = a.running_mean[c];
+      if (a.invstd) a.invstd[o] = invstd;
+      a.scale[o] = sc; a.shift[o] = b - a.running_mean[c] * sc;
+    }
   }
 }
 
@@ -57,6 +70,7 @@ extern "C" int gode_bn_finalize(const gode_bn_finalize_op* op, void* stream) {
   if (!op || op->C <= 0 || !op->scale || !op->shift) return GODE_E_ARG;
   if (op->training) {
     if (!op->stats || !op->mean || !op->invstd || op->ncols % op->C != 0 || op->count <= 0) return GODE_E_ARG;
+    if (op->groups == 2 && (op->rows0 <= 0 || op->rows0 >= op->rows)) return GODE_E_ARG;
   } else if (!op->running_mean || !op->running_var) return GODE_E_ARG;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(op->C), dim3(256), 0, (hipStream_t)stream, *op);
   GODE_LAUNCH_CHECK();
@@ -67,7 +81,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const gode_bn_apply_op a)
   const int64_t n4 = a.M * a.C / 4;
   const float neg = a.act == GODE_ACT_RELU ? 0.f : (a.act == GODE_ACT_LRELU ? 0.2f : 1.f);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)((i * 4) % a.C);
+    const int c = (int)((i * 4) % a.C) + ((a.M0 > 0 && i * 4 >= a.M0 * a.C) ? a.C : 0);   // second image group: + C
     f32x4 v = *reinterpret_cast<const f32x4*>(a.y + i * 4);
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (a.scale) { sc = *reinterpret_cast<const f32x4*>(a.scale + c); sh = *reinterpret_cast<const f32x4*>(a.shift + c); }

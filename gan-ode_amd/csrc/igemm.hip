@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const IgemmArgs a) {
     if (m < P.M) {
       const int qw = m % P.Mw; int t = m / P.Mw;
       const int qh = t % P.Mh; t /= P.Mh;
-      const int qd = t % P.Md; const int img = t / P.Md;
+      const int qd = t % P.Md; const int img = t / P.Md + P.img0;
       base = img * a.gsN;
       bd = qd * a.G.Sd + P.Od; bh = qh * a.G.Sh + P.Oh; bw = qw * a.G.Sw + P.Ow;
       oo = (((img * a.G.Xd + qd * a.G.OSd + P.Pd) * a.G.Xh + qh * a.G.OSh + P.Ph) * a.G.Xw + qw * a.G.OSw + P.Pw) *
@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
     if (m < P.M) {
       const int qw = m % P.Mw; int t = m / P.Mw;
       const int qh = t % P.Mh; t /= P.Mh;
-      const int qd = t % P.Md; const int img = t / P.Md;
+      const int qd = t % P.Md; const int img = t / P.Md + P.img0;
       base = img * a.gsN;
       bd = qd * a.G.Sd + P.Od; bh = qh * a.G.Sh + P.Oh; bw = qw * a.G.Sw + P.Ow;
       oo = (((img * a.G.Xd + qd * a.G.OSd + P.Pd) * a.G.Xh + qh * a.G.OSh + P.Ph) * a.G.Xw + qw * a.G.OSw + P.Pw) *
@@ -970,9 +970,19 @@ static void choose_fast(const gode_igemm_op* op, const IgemmGeom& G, int* tile_o
   }
 }
 
-static int prepare(const gode_igemm_op* op, IgemmArgs* A, int* tile, int* max_mblk, int* rows, SplitPlan* sp) {
+static int prepare(const gode_igemm_op* op, IgemmArgs* A, int* tile, int* max_mblk, int* rows, SplitPlan* sp, int* rows0 = nullptr) {
   int rc = gode_build_igemm_geom(op->g, op->dir, &A->G);
   if (rc) return rc;
+  const bool grouped = op->groups == 2;
+  if (grouped) {
+    // two image groups with SEPARATE BatchNorm partial statistics (one discriminator pass over [real; fake]): the
+    // single FPROP phase becomes two phases over the two halves of the batch, so no tile straddles the groups and
+    // each group's partial-statistics rows are contiguous
+    if (op->dir != GODE_FPROP || op->g.N % 2 != 0 || A->G.nphase != 1) return GODE_E_ARG;
+    A->G.ph[1] = A->G.ph[0];
+    A->G.ph[0].M /= 2; A->G.ph[1].M = A->G.ph[0].M; A->G.ph[1].img0 = op->g.N / 2;
+    A->G.nphase = 2;
+  } else if (op->groups != 0 && op->groups != 1) return GODE_E_ARG;
   static const char* menv = getenv("GODE_IGEMM_MODEL");
   static const bool sweeping = getenv("GODE_IGEMM_SWEEP") != nullptr;     // calibration runs: GODE_IGEMM_FORCE="tile,k" is re-read per call
   const char* fenv = sweeping ? getenv("GODE_IGEMM_FORCE") : nullptr;
@@ -990,6 +1000,10 @@ static int prepare(const gode_igemm_op* op, IgemmArgs* A, int* tile, int* max_mb
   *tile = pick_tile_split_aware(op->g, A->G, op->tile);
   *sp = plan_split(op, A->G, *tile);
   }
+  if (grouped && sp->ksplit > 1 && (sp->positions / 2) % SPLITK_ROWS != 0) {
+    // the split-K finish emits one statistics row per SPLITK_ROWS output positions: the groups must not share a row
+    sp->ksplit = 1; sp->slabs_per_split = 0;
+  }
   const int bm = tile_bm(*tile);
   int r0 = 0, mx = 0;
   for (int i = 0; i < A->G.nphase; ++i) {
@@ -1000,7 +1014,15 @@ static int prepare(const gode_igemm_op* op, IgemmArgs* A, int* tile, int* max_mb
   }
   *max_mblk = mx;
   *rows = sp->ksplit > 1 ? gode_ceil_div(sp->positions, SPLITK_ROWS) : r0;
+  if (rows0) *rows0 = !grouped ? *rows : (sp->ksplit > 1 ? *rows / 2 : A->G.ph[1].row0);
   return 0;
+}
+
+// rows of the partial statistics that belong to image group 0 (grouped FPROP; == gode_igemm_stats_rows otherwise)
+extern "C" int gode_igemm_stats_rows0(const gode_igemm_op* op) {
+  IgemmArgs A; int tile, mx, rows, rows0; SplitPlan sp;
+  int rc = prepare(op, &A, &tile, &mx, &rows, &sp, &rows0);
+  return rc ? rc : rows0;
 }
 
 extern "C" int gode_igemm_stats_rows(const gode_igemm_op* op) {
@@ -1111,7 +1133,7 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
                    (op->scale == nullptr || ((uintptr_t)op->scale % 16 == 0 && (uintptr_t)op->shift % 16 == 0));
   if (((uintptr_t)op->wpack % 16) != 0) return GODE_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  {
+  if (op->groups != 2) {      // (the thin-output streaming kernels below know nothing of image groups; grouped ops carry BN stats)
     int maxM = 0, minK = 1 << 30; bool kp_ok = true;
     for (int i = 0; i < G.nphase; ++i) {
       if (G.ph[i].M > maxM) maxM = G.ph[i].M;

@@ -82,8 +82,16 @@ class ConvStack:
     per call with element strides (discriminators read the caller's video / image in place)."""
 
     def __init__(self, specs: Sequence[LayerSpec], params: Sequence[LayerParams], device, owns_input: bool,
-                 momentum=0.1, eps=1e-5, pack_cache: Optional[dict] = None):
+                 momentum=0.1, eps=1e-5, pack_cache: Optional[dict] = None, groups: int = 1):
+        """groups == 2: ONE pass over two image groups [first source; second source] (a discriminator applied to real
+        and fake in the same launches, specs built for the joint batch): every BatchNorm keeps per-group batch
+        statistics -- exactly what the reference's two forward calls compute -- while the GEMMs, weight gradients and
+        elementwise passes run once over twice the rows.  Conv (FPROP) stacks with caller-owned inputs only."""
         self.specs, self.params, self.device = list(specs), list(params), device
+        self.groups = groups
+        if groups not in (1, 2) or (groups == 2 and (owns_input or specs[0].fwd_dir != L.FPROP or specs[0].has_bn
+                                                     or specs[0].geom.N % 2)):
+            raise ValueError("grouped ConvStack: two groups, Conv stack, caller-owned input, no BatchNorm on layer 0")
         self.nl = len(specs)
         self.momentum, self.eps = momentum, eps
         self.busy = False
@@ -110,13 +118,16 @@ class ConvStack:
             self.wpack_f.append(self._shared_pack(l, s.fwd_dir, n))
             C_out = s.out_dims()[4]
             if s.has_bn:
-                probe = L.IgemmOp(g=s.geom, dir=s.fwd_dir, tile=0)
+                probe = L.IgemmOp(g=s.geom, dir=s.fwd_dir, tile=0, groups=groups)
                 rows = lib.gode_igemm_stats_rows(C.byref(probe))
+                if rows <= 0:
+                    raise RuntimeError(f"layer {l}: no partial-statistics layout for this geometry ({rows})")
                 ncols = self._ncols(s)
                 self.stat_rows.append(rows)
                 self.stats.append(torch.empty(rows * 2 * ncols, **f32))
-                self.mean.append(torch.empty(C_out, **f32)); self.invstd.append(torch.empty(C_out, **f32))
-                self.scale.append(torch.empty(C_out, **f32)); self.shift.append(torch.empty(C_out, **f32))
+                # per-group [groups][C] (group-major)
+                self.mean.append(torch.empty(groups * C_out, **f32)); self.invstd.append(torch.empty(groups * C_out, **f32))
+                self.scale.append(torch.empty(groups * C_out, **f32)); self.shift.append(torch.empty(groups * C_out, **f32))
             else:
                 self.stat_rows.append(0); self.stats.append(None)
                 self.mean.append(None); self.invstd.append(None); self.scale.append(None); self.shift.append(None)
@@ -176,6 +187,8 @@ class ConvStack:
             return False
         prod, cons = self.specs[l], self.specs[l + 1]
         C_out = prod.out_dims()[4]
+        if self.groups == 2 and prod.has_bn:
+            return True      # per-group scale/shift: consumers read the activated copy, nothing downstream knows of groups
         g = cons.geom
         taps = g.kd * g.kh * g.kw
         macs = g.N * g.Do * g.Ho * g.Wo * g.Co * g.Ci * taps
@@ -223,44 +236,74 @@ class ConvStack:
         return tuple((p.weight._version, getattr(p.weight, "_gode_ver", 0)) for p in self.params)
 
     # -- forward -------------------------------------------------------------------------------------------
+    def _half_geom(self, g):
+        h = L.ConvGeom(*g.key())
+        h.N = g.N // 2
+        return h
+
     def _build_fwd(self, training: bool):
         ops = []
         packs = []
         patch = {}
+        lib = L.lib()
+        G2 = self.groups == 2
         for l, (s, p) in enumerate(zip(self.specs, self.params)):
             packs.append((l, s.fwd_dir, L.PackOp(g=s.geom, dir=s.fwd_dir, co_canon=0, w=dptr(p.weight),
                                                  wpack=dptr(self.wpack_f[l]), co_perm=dptr(s.co_perm))))
             sc, sh, act = self._in_xform(l)
             src = self._in_src(l)
+            if G2 and l == 0:
+                # the two groups come from two caller tensors: one launch each into the halves of y[0]
+                hg = self._half_geom(s.geom)
+                half = self.y[0].numel() // 2
+                pair = []
+                for k in range(2):
+                    o = L.IgemmOp(g=hg, dir=s.fwd_dir, act=act, epilogue=s.epilogue, tile=0, src=None,
+                                  wpack=dptr(self.wpack_f[l]), out=self.y[0].data_ptr() + 4 * half * k)
+                    pair.append(o)
+                    ops.append(o)
+                patch["first"], patch["first2"] = pair
+                if self.a[0] is not None:          # activated copy for a heavy consumer (no BatchNorm on layer 0)
+                    d = s.out_dims()
+                    ops.append(L.BnApplyOp(y=dptr(self.y[0]), out=dptr(self.a[0]), scale=None, shift=None,
+                                           M=d[0] * d[1] * d[2] * d[3], C=d[4], act=s.act))
+                continue
+            want_stats = s.has_bn and training
             op = L.IgemmOp(g=s.geom, dir=s.fwd_dir, act=act, epilogue=s.epilogue, tile=0, src=dptr(src),
                            wpack=dptr(self.wpack_f[l]), out=dptr(self.y[l]) if l < self.nl - 1 else None,
                            scale=dptr(sc), shift=dptr(sh),
-                           stats=dptr(self.stats[l]) if (s.has_bn and training) else None)
+                           stats=dptr(self.stats[l]) if want_stats else None,
+                           groups=2 if (G2 and s.has_bn) else 0)
             ops.append(op)
             if l == 0:
                 patch["first"] = op
             if l == self.nl - 1:
                 patch["last"] = op
             if s.has_bn:
+                rows0 = lib.gode_igemm_stats_rows0(C.byref(op)) if G2 else 0
                 ops.append(L.BnFinalizeOp(stats=dptr(self.stats[l]), rows=self.stat_rows[l], ncols=self._ncols(s),
-                                          C=s.out_dims()[4], count=self._count(l), gamma=dptr(p.gamma),
+                                          C=s.out_dims()[4], count=self._count(l) // self.groups, gamma=dptr(p.gamma),
                                           beta=dptr(p.beta), running_mean=dptr(p.running_mean),
                                           running_var=dptr(p.running_var),
                                           num_batches_tracked=dptr(p.num_batches_tracked), mean=dptr(self.mean[l]),
                                           invstd=dptr(self.invstd[l]), scale=dptr(self.scale[l]),
                                           shift=dptr(self.shift[l]), momentum=self.momentum, eps=self.eps,
-                                          training=1 if training else 0))
+                                          training=1 if training else 0, groups=self.groups if G2 else 0, rows0=rows0))
             if l < self.nl - 1 and self.a[l] is not None:
                 d = s.out_dims()
+                M = d[0] * d[1] * d[2] * d[3]
                 ops.append(L.BnApplyOp(y=dptr(self.y[l]), out=dptr(self.a[l]), scale=dptr(self.scale[l]),
-                                       shift=dptr(self.shift[l]), M=d[0] * d[1] * d[2] * d[3], C=d[4], act=s.act))
+                                       shift=dptr(self.shift[l]), M=M, C=d[4], act=s.act,
+                                       M0=M // 2 if (G2 and s.has_bn) else 0))
         patch["packs"] = packs
         self._attach_work([op for op in ops if isinstance(op, L.IgemmOp)])
         return L.Program(ops), patch
 
-    def forward(self, training: bool, x: Optional[torch.Tensor] = None, x_strides=None, pre_ops_program=None):
-        """Runs the stack.  x (+ element strides {N,D,H,W,C}) is required when the plan does not own its input.
-        Returns the freshly allocated last-layer output [N,D,H,W,C]."""
+    def forward(self, training: bool, x: Optional[torch.Tensor] = None, x_strides=None, pre_ops_program=None,
+                x2: Optional[torch.Tensor] = None, x2_strides=None):
+        """Runs the stack.  x (+ element strides {N,D,H,W,C}) is required when the plan does not own its input; a
+        grouped stack takes the second group's tensor as x2.  Returns the freshly allocated last-layer output
+        [N,D,H,W,C] (grouped: N = both groups, first group first)."""
         self._refresh()
         if training not in self._fwd:
             self._fwd[training] = self._build_fwd(training)
@@ -275,6 +318,12 @@ class ConvStack:
             # aliases WITHOUT autograd history: the plan must not keep the caller's graph (or, below, its own autograd
             # node, which holds the plan's lease) alive
             self._x_user, self._x_strides = x.detach(), tuple(int(v) for v in x_strides)
+            if self.groups == 2:
+                second = patch["first2"]
+                second.src = x2.data_ptr()
+                for i in range(5):
+                    second.gs[i] = int(x2_strides[i])
+                self._x2_user, self._x2_strides = x2.detach(), tuple(int(v) for v in x2_strides)
         st = stream_ptr()
         self._run_stale_packs(patch["packs"], st)
         if pre_ops_program is not None:
@@ -320,6 +369,23 @@ class ConvStack:
             sc, sh, act = self._in_xform(l)
             src = self._in_src(l)
             # weight gradient
+            if self.groups == 2 and l == 0:
+                # two caller tensors: one launch per group over its half of g[0], the second adds to the first
+                hg = self._half_geom(s.geom)
+                half = self.g[0].numel() // 2
+                pair = []
+                for k in range(2):
+                    pair.append(L.WgradOp(g=hg, act=act, xform_on_y=0, splits=0, accumulate=0, x=None,
+                                          y=self.g[0].data_ptr() + 4 * half * k, scale=dptr(sc), shift=dptr(sh)))
+                if need_param_grad:
+                    for k, wk in enumerate(pair):
+                        wg_work = max(wg_work, lib.gode_wgrad_work_size(C.byref(wk)))
+                        patch["dw"].append((l, wk, k == 1))
+                        ops.append(wk)
+                    patch["wgrad0"], patch["wgrad0b"] = pair
+                if need_input_grad:
+                    raise NotImplementedError("a grouped stack does not return input gradients")
+                continue
             if s.fwd_dir == L.FPROP:
                 w = L.WgradOp(g=s.geom, act=act, xform_on_y=0, splits=0, accumulate=0, x=dptr(src), y=dptr(self.g[l]),
                               scale=dptr(sc), shift=dptr(sh), co_perm=dptr(s.co_perm))
@@ -328,7 +394,7 @@ class ConvStack:
                               scale=dptr(sc), shift=dptr(sh), co_perm=dptr(s.co_perm))
             if need_param_grad:
                 wg_work = max(wg_work, lib.gode_wgrad_work_size(C.byref(w)))
-                patch["dw"].append((l, w))
+                patch["dw"].append((l, w, False))
                 if l == 0:
                     patch["wgrad0"] = w
                 if l == self.nl - 1 and "tanh" not in patch:
@@ -351,6 +417,23 @@ class ConvStack:
             if l > 0:
                 sp, pp = self.specs[l - 1], self.params[l - 1]
                 M, Cc = self._count(l - 1), sp.out_dims()[4]
+                if sp.has_bn and self.groups == 2:
+                    # per-group batch statistics: the reduction and the correction terms run per half of the rows
+                    half = M // 2
+                    for k in range(2):
+                        off = 4 * half * Cc * k
+                        b = L.BnBwdOp(g=self.g[l - 1].data_ptr() + off, y=self.y[l - 1].data_ptr() + off, M=half, C=Cc,
+                                      act=sp.act, gamma=dptr(pp.gamma), mean=self.mean[l - 1].data_ptr() + 4 * Cc * k,
+                                      invstd=self.invstd[l - 1].data_ptr() + 4 * Cc * k,
+                                      scale=self.scale[l - 1].data_ptr() + 4 * Cc * k,
+                                      shift=self.shift[l - 1].data_ptr() + 4 * Cc * k, accumulate=0,
+                                      eval_mode=0 if training else 1)
+                        bn_work = max(bn_work, lib.gode_bn_bwd_work_size(half, Cc))
+                        if need_param_grad:
+                            patch["dgamma"].append((l - 1, b, k == 1))
+                        patch.setdefault("bnb", []).append(b)
+                        ops.append(b)
+                    continue
                 if sp.has_bn:
                     b = L.BnBwdOp(g=dptr(self.g[l - 1]), y=dptr(self.y[l - 1]), M=M, C=Cc, act=sp.act,
                                   gamma=dptr(pp.gamma), mean=dptr(self.mean[l - 1]), invstd=dptr(self.invstd[l - 1]),
@@ -358,7 +441,7 @@ class ConvStack:
                                   eval_mode=0 if training else 1)
                     bn_work = max(bn_work, lib.gode_bn_bwd_work_size(M, Cc))
                     if need_param_grad:
-                        patch["dgamma"].append((l - 1, b))
+                        patch["dgamma"].append((l - 1, b, False))
                 else:
                     b = L.BnBwdOp(g=dptr(self.g[l - 1]), y=dptr(self.y[l - 1]), M=M, C=Cc, act=sp.act)
                 patch.setdefault("bnb", []).append(b)
@@ -366,7 +449,7 @@ class ConvStack:
         wg_buf = torch.empty(max(wg_work, 1), **f32)
         bn_buf = torch.empty(max(bn_work, 1), **f32)
         patch["keep"] = (wg_buf, bn_buf)      # owned by this program (several backward programs coexist)
-        for _, w in patch["dw"]:
+        for _, w, _f in patch["dw"]:
             w.work = wg_buf.data_ptr()
         for b in patch.get("bnb", []):
             if b.mean:
@@ -377,13 +460,15 @@ class ConvStack:
 
     def _patch_user_input(self, patch):
         if self.x_in is None and "wgrad0" in patch:
-            w0 = patch["wgrad0"]
-            tgt = "x" if self.specs[0].fwd_dir == L.FPROP else "y"
-            if tgt != "x":
+            if self.specs[0].fwd_dir != L.FPROP:
                 raise RuntimeError("caller-owned input is only supported for Conv (FPROP) stacks")
-            w0.x = self._x_user.data_ptr()
-            for i in range(5):
-                w0.xs[i] = self._x_strides[i]
+            srcs = [(patch["wgrad0"], self._x_user, self._x_strides)]
+            if self.groups == 2:
+                srcs.append((patch["wgrad0b"], self._x2_user, self._x2_strides))
+            for w0, xu, xs in srcs:
+                w0.x = xu.data_ptr()
+                for i in range(5):
+                    w0.xs[i] = xs[i]
 
     def backward(self, gout: torch.Tensor, need_input_grad: bool, need_param_grad: bool = True, into=None):
         """gout: gradient wrt the (activated) output, any strides, logical dims = self.out_dims.
@@ -418,13 +503,13 @@ class ConvStack:
             return None, None, g_in
         if into is not None:
             per = {l: t for l, t in enumerate(into)}
-            for l, w in patch["dw"]:
+            for l, w, force in patch["dw"]:
                 w.dw = per[l][0].data_ptr()
-                w.accumulate = 1 if per[l][3] else 0
-            for l, b in patch["dgamma"]:
+                w.accumulate = 1 if (per[l][3] or force) else 0
+            for l, b, force in patch["dgamma"]:
                 b.dgamma = per[l][1].data_ptr()
                 b.dbeta = per[l][2].data_ptr()
-                b.accumulate = 1 if per[l][3] else 0
+                b.accumulate = 1 if (per[l][3] or force) else 0
             self._patch_user_input(patch)
             prog.run(stream_ptr())
             self.busy = False
@@ -442,13 +527,13 @@ class ConvStack:
                 bv = flat[off:off + c]; off += c
             per_layer[l] = (wv, gv, bv)
             views.append((wv, gv, bv))
-        for l, w in patch["dw"]:
+        for l, w, force in patch["dw"]:
             w.dw = per_layer[l][0].data_ptr()
-            w.accumulate = 0
-        for l, b in patch["dgamma"]:
+            w.accumulate = 1 if force else 0
+        for l, b, force in patch["dgamma"]:
             b.dgamma = per_layer[l][1].data_ptr()
             b.dbeta = per_layer[l][2].data_ptr()
-            b.accumulate = 0
+            b.accumulate = 1 if force else 0
         self._patch_user_input(patch)
         prog.run(stream_ptr())
         self.busy = False

@@ -818,6 +818,49 @@ class _DiscFn(torch.autograd.Function):
         return (None, None, None, None, None, gx, *grads)
 
 
+class _DiscPairFn(torch.autograd.Function):
+    """One pass of a discriminator over [first; second] (real and fake batches of equal shape) with per-group BatchNorm
+    statistics: returns the joint raw output [2B, Do, Ho, Wo, 1]."""
+
+    @staticmethod
+    def forward(ctx, plan, strides1, strides2, training, keep, arena, x1, x2, *params):
+        out = plan.forward(training, x=x1, x_strides=strides1, x2=x2, x2_strides=strides2)
+        plan.busy = keep
+        ctx.plan = plan
+        ctx.lease = _Lease(plan)
+        ctx.arena = arena
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        plan = ctx.plan
+        ctx.lease.check("discriminator (paired pass)")
+        if ctx.needs_input_grad[6] or ctx.needs_input_grad[7]:
+            raise NotImplementedError("the paired discriminator pass is for discriminator updates (detached inputs)")
+        need_p = any(ctx.needs_input_grad[8:])
+        arena = ctx.arena
+        nparams = len(ctx.needs_input_grad) - 8
+        into = None
+        if need_p and arena is not None and arena.active:
+            into = []
+            for lp in plan.params:
+                wt, acc = arena.target(lp.weight)
+                gt = bt = None
+                if lp.gamma is not None:
+                    gt, _ = arena.target(lp.gamma)
+                    bt, _ = arena.target(lp.beta)
+                into.append((wt, gt, bt, acc))
+        flat, views, _ = plan.backward(gout, need_input_grad=False, need_param_grad=need_p, into=into)
+        grads = [None] * nparams
+        if into is None and need_p:
+            grads = []
+            for wv, gv, bv in views:
+                grads.append(wv)
+                if gv is not None:
+                    grads += [gv, bv]
+        return (None, None, None, None, None, None, None, None, *grads)
+
+
 class _DiscBase(nn.Module):
     _gode_direct_grads = True
 
@@ -873,6 +916,54 @@ class _DiscBase(nn.Module):
         if input.dim() == 4:
             h = h[:, :, 0]
         return h.squeeze(), None
+
+
+    @staticmethod
+    def _strides5(x):
+        if x.dim() == 5:
+            return (x.stride(0), x.stride(2), x.stride(3), x.stride(4), x.stride(1))
+        return (x.stride(0), 0, x.stride(2), x.stride(3), x.stride(1))
+
+    def forward_pair_joint(self, first, second):
+        """D(first) and D(second) in ONE pass -- the same launches over [first; second] with PER-GROUP BatchNorm batch
+        statistics, i.e. the arithmetic of the reference's two calls `dis(real)`, `dis(fake)` (mnist_moco_ode.py:119-124,
+        137-143): running statistics receive first's update, then second's.  Returns the joint raw logits
+        [2B, Do, Ho, Wo, 1] (first group first); GanTrainer feeds them to bce_with_logits_halves.  Twice the rows per
+        launch fill the GPU better (video-D GEMMs +14 %) and every elementwise / reduction launch is issued once."""
+        _require_gpu(self.main[1].weight, type(self).__name__)
+        for t in (first, second):
+            _require_gpu(t, type(self).__name__ + " input")
+            if t.dtype != torch.float32:
+                raise RuntimeError("fp32 input expected")
+        if tuple(first.shape) != tuple(second.shape):
+            raise RuntimeError("paired pass: both inputs must have the same shape")
+        if first.requires_grad or second.requires_grad:
+            raise RuntimeError("paired pass: inputs must be detached (it is the discriminator-update pass)")
+        joint_shape = (2 * first.shape[0],) + tuple(first.shape[1:])
+        key = ("pair",) + tuple(first.shape)
+        plan = self._pool.get(key, lambda: ConvStack(self._specs(joint_shape), self._layer_params(),
+                                                     self.main[1].weight.device, owns_input=False,
+                                                     pack_cache=self._pool.pack_cache, groups=2))
+        params = []
+        for p in self._layer_params():
+            params.append(p.weight)
+            if p.gamma is not None:
+                params += [p.gamma, p.beta]
+        keep = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _DiscPairFn.apply(plan, self._strides5(first), self._strides5(second), self.training, keep,
+                                 getattr(self, "_gode_arena", None), first, second, *params)
+
+    def forward_pair(self, first, second):
+        """-> ((logits_first, None), (logits_second, None)) with forward()'s shapes."""
+        out = self.forward_pair_joint(first, second)
+        B = first.shape[0]
+        res = []
+        for h in (out[:B], out[B:]):
+            h = h.permute(0, 4, 1, 2, 3)
+            if first.dim() == 4:
+                h = h[:, :, 0]
+            res.append((h.squeeze(), None))
+        return tuple(res)
 
 
 class PatchImageDiscriminator(_DiscBase):

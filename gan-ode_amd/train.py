@@ -114,6 +114,37 @@ def bce_with_logits_const(logits: torch.Tensor, target: float) -> torch.Tensor:
     return _BceConstFn.apply(logits, target)
 
 
+class _BceHalvesFn(torch.autograd.Function):
+    """bce(x[:B], t_first) + bce(x[B:], t_second), each mean-reduced over its half, on ONE joint logits tensor (the
+    paired discriminator pass): one autograd node, the gradient is one tensor in the joint layout."""
+
+    @staticmethod
+    def forward(ctx, joint, t_first, t_second):
+        x = joint.contiguous()
+        n = x.numel() // 2
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x)
+        st = stream_ptr()
+        for k, tgt in enumerate((t_first, t_second)):
+            L.run_one(L.BceOp(logits=x.data_ptr() + 4 * n * k, grad=grad.data_ptr() + 4 * n * k, loss=loss.data_ptr(), n=n,
+                              target=float(tgt), gscale=1.0, accumulate=k), st)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return _scaled(grad, gout), None, None
+
+
+def bce_with_logits_halves(joint: torch.Tensor, target_first: float, target_second: float) -> torch.Tensor:
+    """nn.BCEWithLogitsLoss()(x[:B], t1) + nn.BCEWithLogitsLoss()(x[B:], t2) for the joint output of
+    forward_pair_joint (mnist_moco_ode.py:126-128,145-147)."""
+    if not joint.is_cuda or joint.shape[0] % 2:
+        raise RuntimeError("bce_with_logits_halves: a CUDA tensor with an even leading dimension is expected")
+    return _BceHalvesFn.apply(joint, target_first, target_second)
+
+
 def bce_with_logits_pair(logits_a, target_a: float, logits_b, target_b: float) -> torch.Tensor:
     """bce_with_logits_const(a, ta) + bce_with_logits_const(b, tb) as one node (same arithmetic: each term is
     mean-reduced on its own, the two means are added in fp32)."""
@@ -425,7 +456,7 @@ class GanTrainer:
 
     def __init__(self, gen, dis_vid, dis_img, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5, d_iters=2,
                  process_group=None, freeze_d_in_g_step=True, freeze_gc=False, direct_grads=True, sync_replicas=True,
-                 overlap_image_d=True, graph=False):
+                 overlap_image_d=True, graph=False, pair_d_passes=True):
         self.gen, self.dis_vid, self.dis_img = gen, dis_vid, dis_img
         mk = lambda m: FusedAdam(m.parameters(), lr=lr, betas=betas, weight_decay=weight_decay)  # noqa: E731
         self.gen_opt, self.vid_opt, self.img_opt = mk(gen), mk(dis_vid), mk(dis_img)
@@ -440,6 +471,9 @@ class GanTrainer:
         # Everything that touches the generator stays on the caller's stream in program order (its BatchNorm running
         # statistics are updated by every sample_* call), each stream executes the same kernels in the same order as
         # the serial schedule, so results are bit-identical to overlap_image_d=False.
+        # pair_d_passes: in the discriminator steps D(real) and D(fake) run as ONE pass over [real; fake] with per-group
+        # BatchNorm statistics (forward_pair_joint): same arithmetic per element, half the launches, fuller GEMM grids.
+        self.pair_d = bool(pair_d_passes)
         self._side = None
         if overlap_image_d and next(dis_img.parameters()).is_cuda:
             self._side = torch.cuda.Stream(device=next(dis_img.parameters()).device)
@@ -526,8 +560,9 @@ class GanTrainer:
         losses = []
         for x in shards:
             B = x.shape[0]
-            with on_side():
-                pr, _ = self.dis_img(x)
+            if not self.pair_d:
+                with on_side():
+                    pr, _ = self.dis_img(x)
             with torch.no_grad():
                 fake, _ = self.gen.sample_images(B)      # generator work stays on the caller's stream
             if side is not None:
@@ -536,8 +571,11 @@ class GanTrainer:
                 side.wait_event(ev)
                 fake.record_stream(side)
             with on_side():
-                pf, _ = self.dis_img(fake)
-                loss = bce_with_logits_pair(pr, 1.0, pf, 0.0)
+                if self.pair_d:
+                    loss = bce_with_logits_halves(self.dis_img.forward_pair_joint(x, fake), 1.0, 0.0)
+                else:
+                    pf, _ = self.dis_img(fake)
+                    loss = bce_with_logits_pair(pr, 1.0, pf, 0.0)
                 loss.backward(gradient=unit_grad(loss.device))
             losses.append(loss.detach())
         with on_side():
@@ -560,11 +598,16 @@ class GanTrainer:
         losses = []
         for x in shards:
             B = x.shape[0]
-            pr, _ = self.dis_vid(x.transpose(1, 2))             # [B,T,C,H,W] -> [B,C,T,H,W] view, read in place
+            real = x.transpose(1, 2)                            # [B,T,C,H,W] -> [B,C,T,H,W] view, read in place
+            if not self.pair_d:
+                pr, _ = self.dis_vid(real)
             with torch.no_grad():
                 fake, _ = self.gen.sample_videos(B)
-            pf, _ = self.dis_vid(fake)
-            loss = bce_with_logits_pair(pr, 1.0, pf, 0.0)
+            if self.pair_d:
+                loss = bce_with_logits_halves(self.dis_vid.forward_pair_joint(real, fake), 1.0, 0.0)
+            else:
+                pf, _ = self.dis_vid(fake)
+                loss = bce_with_logits_pair(pr, 1.0, pf, 0.0)
             loss.backward(gradient=unit_grad(loss.device))
             losses.append(loss.detach())
         self._opt_step(self.dis_vid, self.vid_opt, len(shards))

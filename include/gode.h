@@ -61,12 +61,19 @@ typedef struct gode_igemm_op {
   float* stats;
   int64_t gs[5];
   float* work; /* nullable; >= gode_igemm_work_size floats enables split-K for launches that would not fill the GPU */
+  /* groups == 2 (FPROP with stats only, N even): the batch is two image groups [0, N/2) and [N/2, N) whose BatchNorm
+   * partial statistics must stay separate -- one discriminator pass over [real; fake] keeps the per-pass batch
+   * statistics of the reference's two calls (mnist_moco_ode.py:119-124,137-143).  The partial-statistics rows of group 0
+   * are the first gode_igemm_stats_rows0(op) rows of every column, group 1 the rest.  0 / 1: one group. */
+  int32_t groups, pad3_;
 } gode_igemm_op;
 int gode_igemm(const gode_igemm_op* op, void* stream);
 /* floats of workspace the op can use for split-K (0: it never splits).  Deterministic from the op's geometry. */
 int64_t gode_igemm_work_size(const gode_igemm_op* op);
 /* number of partial-stats rows gode_igemm writes for this op (host-side, no GPU work) */
 int gode_igemm_stats_rows(const gode_igemm_op* op);
+/* rows of those that belong to image group 0 (== gode_igemm_stats_rows unless op->groups == 2) */
+int gode_igemm_stats_rows0(const gode_igemm_op* op);
 /* floats needed for the packed weights of (geom, dir) */
 int64_t gode_pack_size(const gode_conv_geom* g, int dir);
 /* canonical W[co][ci][taps] -> packed panels.  co_perm (nullable, length g->Co): internal y-side channel c is
@@ -106,6 +113,10 @@ typedef struct gode_bn_finalize_op {
   float* running_mean; float* running_var; int64_t* num_batches_tracked;
   float* mean; float* invstd; float* scale; float* shift;
   float momentum, eps; int32_t training, pad_;
+  /* groups == 2: the first rows0 partial rows belong to image group 0, the rest to group 1 (count = elements per channel
+   * and GROUP); mean / invstd / scale / shift are [2][C] (group-major); the running statistics receive the two
+   * momentum updates in group order (what two successive forward calls do), num_batches_tracked += 2. */
+  int32_t groups, rows0;
 } gode_bn_finalize_op;
 int gode_bn_finalize(const gode_bn_finalize_op* op, void* stream);
 
@@ -114,6 +125,7 @@ int gode_bn_finalize(const gode_bn_finalize_op* op, void* stream);
  * in their operand path; light layers keep it fused).  scale==NULL: plain activation. */
 typedef struct gode_bn_apply_op {
   const float* y; float* out; const float* scale; const float* shift; int64_t M; int32_t C, act;
+  int64_t M0; /* > 0: rows >= M0 use scale + C / shift + C (second image group of a grouped pass); 0: one group */
 } gode_bn_apply_op;
 int gode_bn_apply(const gode_bn_apply_op* op, void* stream);
 

@@ -246,3 +246,92 @@ def test_graph_replayed_iterations_are_bitwise_the_eager_ones():
         assert torch.equal(a, b)
     assert torch.equal(runs[0][2][0], runs[1][2][0])
     assert runs[0][3] == runs[1][3] == [12, 6]
+
+
+@pytest.mark.parametrize("which", ["video", "image"])
+def test_paired_discriminator_pass_equals_two_passes(which):
+    """forward_pair(real, fake): ONE pass over [real; fake] with per-group BatchNorm statistics against the two separate
+    calls of the reference loop (mnist_moco_ode.py:119-124,137-143) on the same module: logits and running statistics to
+    fp32 rounding (1e-5), weight gradients to fp32 summation order (one reduction over both groups instead of store +
+    add), running statistics updated real-then-fake, num_batches_tracked += 2;
+    against the oracle at the usual tolerances; eval mode too."""
+    seed_all(41)
+    if which == "video":
+        dis, ref = G.VideoDiscriminator(1, ksize=2, ndf=16), M.VideoDisc(1, ksize=2, ndf=16)
+        real = torch.rand(6, 16, 1, 28, 28, generator=torch.Generator().manual_seed(1)).transpose(1, 2)   # strided view, as the loop feeds it
+        fake = torch.rand(6, 1, 16, 28, 28, generator=torch.Generator().manual_seed(2)) * 2 - 1
+    else:
+        dis, ref = G.PatchImageDiscriminator(1, ndf=16), M.PatchImageDisc(1, ndf=16)
+        real = torch.rand(6, 1, 28, 28, generator=torch.Generator().manual_seed(1))
+        fake = torch.rand(6, 1, 28, 28, generator=torch.Generator().manual_seed(2)) * 2 - 1
+    ref.load_state_dict(dis.state_dict())
+    import copy
+    dis2 = copy.deepcopy(dis)
+    dis.cuda(); dis2.cuda()
+    rc, fc = real.cuda(), fake.cuda()
+    (pr, _), (pf, _) = dis.forward_pair(rc, fc)
+    loss = G.bce_with_logits_pair(pr, 1.0, pf, 0.0)
+    loss.backward()
+    qr, _ = dis2(rc)
+    qf, _ = dis2(fc)
+    loss2 = G.bce_with_logits_pair(qr, 1.0, qf, 0.0)
+    loss2.backward()
+    assert pr.shape == qr.shape and pf.shape == qf.shape
+    # (not bitwise: the paired stack reads materialised activations where the single pass fuses BatchNorm into the load,
+    # and tile / split-K choices depend on the row count)
+    assert rel_err(pr.detach().cpu(), qr.detach().cpu()) < 1e-5 and rel_err(pf.detach().cpu(), qf.detach().cpu()) < 1e-5
+    assert abs(float(loss) - float(loss2)) < 1e-6
+    for (k, p), (_, q) in zip(dis.named_parameters(), dis2.named_parameters()):
+        assert rel_err(p.grad.cpu(), q.grad.cpu()) < 2e-5, k
+    for (k, v), (_, w) in zip(dis.state_dict().items(), dis2.state_dict().items()):
+        assert rel_err(v.cpu().double(), w.cpu().double()) < 1e-5, k    # weights untouched, running statistics + counters agree
+    # the oracle's two calls
+    bce = torch.nn.BCEWithLogitsLoss()
+    orr, _ = ref(real)
+    orf, _ = ref(fake)
+    ol = bce(orr, torch.ones_like(orr)) + bce(orf, torch.zeros_like(orf))
+    ol.backward()
+    assert rel_err(pr.detach().cpu(), orr.detach()) < TOL and rel_err(pf.detach().cpu(), orf.detach()) < TOL
+    assert abs(float(loss) - float(ol)) / abs(float(ol)) < TOL
+    for (k, p), (_, q) in zip(dis.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad.cpu(), q.grad) < 5e-4, k
+    for (k, v), (_, w) in zip(dis.state_dict().items(), ref.state_dict().items()):
+        if "running_" in k:
+            assert rel_err(v.cpu(), w) < TOL, k
+        if "num_batches" in k:
+            assert int(v) == int(w) == 2, k
+    # the joint form the trainer uses, and eval mode (running statistics for both groups)
+    joint = dis.forward_pair_joint(rc, fc)
+    lj = G.bce_with_logits_halves(joint, 1.0, 0.0)
+    (pr2, _), (pf2, _) = dis2.forward_pair(rc, fc)
+    assert abs(float(lj) - float(G.bce_with_logits_pair(pr2, 1.0, pf2, 0.0))) < 1e-6
+    ref.load_state_dict({k: v.cpu() for k, v in dis.state_dict().items()})     # (dis has seen two more training passes)
+    dis.eval(); ref.eval()
+    with torch.no_grad():
+        (er, _), (ef, _) = dis.forward_pair(rc, fc)
+        wr, _ = ref(real)
+        wf, _ = ref(fake)
+    assert rel_err(er.cpu(), wr) < TOL and rel_err(ef.cpu(), wf) < TOL
+
+
+def test_trainer_with_paired_passes_matches_the_two_pass_schedule():
+    """GanTrainer(pair_d_passes=True) (default) against pair_d_passes=False over three iterations: the same losses to
+    fp32 rounding of the weight-gradient sums (and the same statistics), on the full-width MNIST networks at batch 8."""
+    runs = []
+    for pair in (True, False):
+        seed_all(45)
+        gen, dv, di = G.build_mnist()
+        gen.cuda(); dv.cuda(); di.cuda()
+        tr = G.GanTrainer(gen, dv, di, pair_d_passes=pair)
+        rng = torch.Generator().manual_seed(11)
+        losses = []
+        for it in range(2):
+            imgs = [torch.rand(8, 1, 28, 28, generator=rng).cuda() for _ in range(2)]
+            vids = [torch.rand(8, 16, 1, 28, 28, generator=rng).cuda() for _ in range(2)]
+            seed_all(400 + it)
+            losses.append([float(v) for v in tr.step(imgs, vids)])
+        runs.append((losses, {k: v.detach().clone() for m in (dv, di) for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}))
+    assert np.allclose(runs[0][0][0], runs[1][0][0], rtol=1e-5, atol=0), runs          # first iteration: same weights
+    assert np.allclose(runs[0][0][1], runs[1][0][1], rtol=1e-3, atol=0), runs          # after Adam steps: sign-like updates
+    for k in runs[0][1]:
+        assert rel_err(runs[0][1][k].cpu().double(), runs[1][1][k].cpu().double()) < 5e-3, k

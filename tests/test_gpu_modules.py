@@ -454,7 +454,7 @@ def test_data_parallel_step_path_on_one_rank_nccl():
                 load_sd(m, g, f"w0/{p}")
                 m.cuda()
             nets.append((gen, dv, di))
-        tr_dp = G.GanTrainer(*nets[0])
+        tr_dp = G.GanTrainer(*nets[0], pair_d_passes=False)   # (the reference sequence below is the two-pass form)
         tr_dp.world = 2                                   # pretend there is a second rank
         tr_ref = G.GanTrainer(*nets[1])
         real_img = _f32(g["real_img/0/0"]).cuda()
