@@ -12,4 +12,4 @@ CSV=$(find /tmp/prof_$TAG -name '*kernel_trace.csv' | head -1)
 python3 scripts/summarise_iter.py $CSV > $OUT/${TAG}_iter_kernels.txt
 STATS=$(find /tmp/prof_$TAG -name '*kernel_stats.csv' | head -1)
 cp $STATS $OUT/${TAG}_iter_kernel_stats.csv
-python3 scripts/iter_overlap.py $CSV | tee $OUT/${TAG}_iter_overlap.txt; head -12 $OUT/${TAG}_iter_kernels.txt
+python3 scripts/iter_top_dispatches.py $CSV 40 > $OUT/${TAG}_iter_top.txt; python3 scripts/iter_overlap.py $CSV | tee $OUT/${TAG}_iter_overlap.txt; head -12 $OUT/${TAG}_iter_kernels.txt
