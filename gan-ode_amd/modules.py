@@ -814,7 +814,7 @@ class _DiscFn(torch.autograd.Function):
         gx = None
         if need_x:
             g = g_in                                       # [N, D, H, W, C] channels-last, allocated for this call
-            gx = g.permute(0, 4, 1, 2, 3) if len(ctx.x_shape) == 5 else g[:, 0].permute(0, 3, 1, 2)
+            gx = g.permute(0, 4, 1, 2, 3) if len(ctx.x_shape) == 5 else g.squeeze(1).permute(0, 3, 1, 2)
         return (None, None, None, None, None, gx, *grads)
 
 
@@ -914,7 +914,7 @@ class _DiscBase(nn.Module):
         out = _DiscFn.apply(plan, strides, self.training, keep, getattr(self, "_gode_arena", None), x, *params)      # [B, Do, Ho, Wo, 1]
         h = out.permute(0, 4, 1, 2, 3)
         if input.dim() == 4:
-            h = h[:, :, 0]
+            h = h.squeeze(2)       # (a squeeze, not h[:, :, 0]: select's backward allocates a zero tensor and copies)
         return h.squeeze(), None
 
 
@@ -961,7 +961,7 @@ class _DiscBase(nn.Module):
         for h in (out[:B], out[B:]):
             h = h.permute(0, 4, 1, 2, 3)
             if first.dim() == 4:
-                h = h[:, :, 0]
+                h = h.squeeze(2)
             res.append((h.squeeze(), None))
         return tuple(res)
 
