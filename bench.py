@@ -252,6 +252,13 @@ def _rank_main(a):
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     distributed = world > 1 or os.environ.get("GODE_FORCE_DIST") == "1"   # (the latter: rehearse the RCCL path on 1 GPU)
+    out = sys.stdout
+    if distributed:
+        # RCCL prints a version banner on the C-level stdout at initialisation; the contract is ONE JSON line on stdout.
+        # Keep a private handle on the real stdout for that line and route everything else written to fd 1 to stderr.
+        sys.stdout.flush()
+        out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
     ndev = torch.cuda.device_count()
     if a.backend == "nccl" and world > ndev:
         raise SystemExit(f"{world} ranks but {ndev} GPUs visible (RCCL needs one device per rank)")
@@ -282,7 +289,8 @@ def _rank_main(a):
         gen.ode_method = a.ode_method
 
     if a.roofline_only:
-        print(json.dumps({"roofline": _kernel_roofline(gen)}))
+        out.write(json.dumps({"roofline": _kernel_roofline(gen)}) + "\n")
+        out.flush()
         return
 
     # the trainer broadcasts rank 0's parameters and buffers to every replica when world > 1
@@ -296,7 +304,8 @@ def _rank_main(a):
             tr.step(imgs, vids)
         it_ms = _timed(lambda: tr.step(imgs, vids), a.iteration_only, 0, distributed) / a.iteration_only * 1e3
         if rank == 0:
-            print(json.dumps({"iteration_ms": round(it_ms, 3), "iterations": a.iteration_only}))
+            out.write(json.dumps({"iteration_ms": round(it_ms, 3), "iterations": a.iteration_only}) + "\n")
+            out.flush()
         if distributed:
             dist.destroy_process_group()
         return
@@ -383,8 +392,8 @@ def _rank_main(a):
             "allreduce": allreduce,
             "roofline": roof, "iteration": it_roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
-        sys.stdout.flush()
+        out.write(json.dumps(line) + "\n")
+        out.flush()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
