@@ -24,6 +24,8 @@ extern "C" int gode_sizeof(int kind) {
 
 // Executes a pre-built list of ops back to back on one stream: one host->library call per network pass keeps the
 // launch path short at batch 32, where a whole generator forward is ~1 ms of GPU time.
+extern "C" int gode_pack_batch_(const gode_pack_op* const* ops, int n, void* stream);   // igemm.hip
+
 extern "C" int gode_run(const int32_t* kinds, const void* const* ops, int32_t n, void* stream) {
   if (n < 0 || (n > 0 && (!kinds || !ops))) return GODE_E_ARG;
   for (int i = 0; i < n; ++i) {
@@ -41,8 +43,11 @@ extern "C" int gode_run(const int32_t* kinds, const void* const* ops, int32_t n,
       case GODE_OP_ODERNN_BWD: rc = gode_odernn_bwd((const gode_odernn_bwd_op*)ops[i], stream); break;
       case GODE_OP_BN_APPLY: rc = gode_bn_apply((const gode_bn_apply_op*)ops[i], stream); break;
       case GODE_OP_PACK: {
-        const gode_pack_op* p = (const gode_pack_op*)ops[i];
-        rc = gode_pack_weights(&p->g, p->dir, p->w, p->wpack, p->co_perm, p->co_canon, stream);
+        // every run of consecutive pack ops goes out as one launch per 8 panels
+        int j = i;
+        while (j + 1 < n && kinds[j + 1] == GODE_OP_PACK) ++j;
+        rc = gode_pack_batch_((const gode_pack_op* const*)(ops + i), j - i + 1, stream);
+        if (rc == 0) i = j;
         break;
       }
       default: return GODE_E_KIND;

@@ -1220,6 +1220,79 @@ extern "C" int64_t gode_pack_size(const gode_conv_geom* g, int dir) {
   return rc ? rc : gode_pack_floats(G);
 }
 
+// Several panels in one launch (gode_run hands over every run of consecutive pack ops: after an optimiser step all
+// panels of a network are stale at once, and ten 6-us launches cost more than the 20 MB they move).  The entries
+// travel by value in the kernel arguments, so only what the index map needs is kept per phase.
+#define PACK_BATCH 8
+struct PackPhase { int32_t Th, Tw, K, Kp, kd0, kh0, kw0, pad_; int64_t w_off, total; };
+struct PackEntry {
+  const float* w; float* wp; const int32_t* co_perm;
+  int32_t nphase, Cg, fullk, dir, ks_d, ks_h, ks_w, Ci, kd, kh, kw, pad_;
+  PackPhase ph[GODE_MAX_PHASES];
+};
+struct PackBatch { PackEntry e[PACK_BATCH]; };
+static_assert(sizeof(PackBatch) <= 4096, "kernel-argument budget");
+
+// same map as gode_pack_source (conv_geom.h), on the trimmed entry
+__global__ void __launch_bounds__(256) pack_batch_kernel(const PackBatch b) {
+  const PackEntry& E = b.e[blockIdx.z];
+  if ((int)blockIdx.y >= E.nphase) return;
+  const PackPhase& P = E.ph[blockIdx.y];
+  const int taps = E.kd * E.kh * E.kw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P.total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i / P.Kp), k = (int)(i - (int64_t)n * P.Kp);
+    float v = 0.f;
+    if (k < P.K) {
+      int co, ci, kd, kh, kw;
+      if (E.fullk) {
+        const int tapn = n / E.Ci;
+        ci = n - tapn * E.Ci; co = k;
+        kd = tapn / (E.kh * E.kw); kh = (tapn / E.kw) % E.kh; kw = tapn % E.kw;
+      } else {
+        const int tap = k / E.Cg, c = k - tap * E.Cg;
+        const int jw = tap % P.Tw, jh = (tap / P.Tw) % P.Th, jd = tap / (P.Tw * P.Th);
+        kd = P.kd0 + jd * E.ks_d; kh = P.kh0 + jh * E.ks_h; kw = P.kw0 + jw * E.ks_w;
+        if (E.dir == GODE_FPROP) { co = n; ci = c; } else { co = c; ci = n; }
+      }
+      if (E.co_perm) co = E.co_perm[co];
+      if (co >= 0) v = E.w[((int64_t)co * E.Ci + ci) * taps + (kd * E.kh + kh) * E.kw + kw];
+    }
+    E.wp[P.w_off + i] = v;
+  }
+}
+
+extern "C" int gode_pack_batch_(const gode_pack_op* const* ops, int n, void* stream) {
+  for (int at = 0; at < n; at += PACK_BATCH) {
+    PackBatch B;
+    const int cnt = n - at < PACK_BATCH ? n - at : PACK_BATCH;
+    int64_t mx = 0;
+    for (int e = 0; e < cnt; ++e) {
+      const gode_pack_op* op = ops[at + e];
+      if (!op || !op->w || !op->wpack) return GODE_E_ARG;
+      IgemmGeom G;
+      const int rc = gode_build_igemm_geom(op->g, op->dir, &G);
+      if (rc) return rc;
+      PackEntry& E = B.e[e];
+      E.w = op->w; E.wp = op->wpack; E.co_perm = op->co_perm;
+      E.nphase = G.nphase; E.Cg = G.Cg; E.fullk = G.fullk; E.dir = op->dir;
+      E.ks_d = G.kstep_d; E.ks_h = G.kstep_h; E.ks_w = G.kstep_w;
+      E.Ci = op->g.Ci; E.kd = op->g.kd; E.kh = op->g.kh; E.kw = op->g.kw; E.pad_ = 0;
+      for (int i = 0; i < G.nphase; ++i) {
+        const PhaseGeom& p = G.ph[i];
+        PackPhase& q = E.ph[i];
+        q.Th = p.Th; q.Tw = p.Tw; q.K = p.K; q.Kp = p.Kp; q.kd0 = p.kd0; q.kh0 = p.kh0; q.kw0 = p.kw0; q.pad_ = 0;
+        q.w_off = p.w_off; q.total = (int64_t)G.Ncols * p.Kp;
+        if (q.total > mx) mx = q.total;
+      }
+    }
+    if (mx == 0) continue;
+    int blocks = (int)((mx + 1023) / 1024); if (blocks > 512) blocks = 512; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(blocks, GODE_MAX_PHASES, cnt), dim3(256), 0, (hipStream_t)stream, B);
+    GODE_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 extern "C" int gode_pack_weights(const gode_conv_geom* g, int dir, const float* w, float* wpack, const int32_t* co_perm,
                                  int32_t co_canon, void* stream) {
   (void)co_canon;
