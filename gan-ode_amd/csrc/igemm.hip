@@ -29,6 +29,7 @@ struct IgemmArgs {
   int32_t gsN, gsD, gsH, gsW, gsC;
   int32_t act, epilogue;
   int32_t MB, NB, xcd_mode;   // FAST kernel: 1-D grid of MB*NB*nphase workgroups, decoded XCD-aware (see igemm_block_id)
+  int32_t tapskip, dmajor;           // FAST kernel MODE 3; dmajor > 0: rows are (depth, image, h, w)-ordered with this many images
   int32_t stagger;                   // tuning knob: de-phase co-resident workgroups (units of s_sleep 64)
   int32_t ksplit, slabs_per_split;   // split-K: grid is ksplit copies of the above; partial tiles go to work
   float* work;
@@ -267,6 +268,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const IgemmArgs a) {
 }
 
 __device__ __attribute__((aligned(16))) const float gode_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+#define IGEMM_MAX_LIVE_TAPS 64   // MODE 3 tap table (+1 slot read past the end)
 
 // ---------------------------------------------------------------------------------------------------------------
 // FAST variant for the layers that carry the FLOPs: vector gather, Cg % 32 == 0 (so a 32-wide K slab never straddles
@@ -279,9 +281,13 @@ __device__ __attribute__((aligned(16))) const float gode_zero16[4] = {0.f, 0.f, 
 // MODE 2 (LDS-DMA): the slab is written to LDS by `global_load_lds_dwordx4` (no VGPR round trip, no ds_write pass);
 //           two unpadded LDS buffers whose 16-byte chunks are XOR-swizzled through the SOURCE address (the DMA
 //           destination is lane-linear), one barrier per slab.  Transform-free instantiation only.
+// MODE 3 : MODE 2 over the LIVE taps of the tile only: taps that no row of the tile can use -- the depth planes beyond the
+//           tensor's ends in the input gradient of a temporal k=4 convolution, 23-43 % of the K loop of the UCF video
+//           discriminator's layers -- are left out of a per-tile tap table (workgroup-uniform).  Its own instantiation:
+//           the bookkeeping costs the plain MODE 2 loop 5-12 % when compiled in.
 template <int WM, int WN, int TM, int TN, int MODE, bool XF>
 __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs a) {
-  constexpr bool DB = MODE == 1, GL = MODE == 2;
+  constexpr bool DB = MODE == 1, GL = MODE >= 2, SK = MODE == 3;
   static_assert(!(GL && XF), "the LDS-DMA path cannot transform on load");
   constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32, LDK = GL ? 32 : 36;
   constexpr int RPP = NT / 8;
@@ -290,9 +296,11 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
   static_assert(!GL || RPP % 16 == 0, "swizzle key must not depend on the loader pass");
   constexpr int BUF = (BM + BN) * LDK;
   constexpr int NBUF = (DB || GL) ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) float smem[NBUF * BUF + BM * 5];
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * BUF + BM * 5 + (MODE == 3 ? 4 + IGEMM_MAX_LIVE_TAPS : 0)];
   int* rowinfo = reinterpret_cast<int*>(smem + NBUF * BUF);
   int* outoff = rowinfo + BM * 4;
+  int* tapmask = outoff + BM;      // MODE 3 [3]: per dim, bit j set <=> some row of the tile gathers inside the tensor at tap j;
+  int* taptab = tapmask + 4;       //        [3] = number of live taps, taptab[] = their indices in K order
 
   int mblk, nblk, phase, split;
   igemm_block_id(a, mblk, nblk, phase, split);
@@ -306,22 +314,47 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
   const int wm = wave / WN, wn = wave % WN;
   const int Cg = a.G.Cg, Ncols = a.G.Ncols;
 
+  if (SK && tid < 3) tapmask[tid] = 0;
+  if (SK) __syncthreads();
   for (int r = tid; r < BM; r += NT) {
     const int m = mblk * BM + r;
     int base = -1, bd = 0, bh = 0, bw = 0, oo = -1;
     if (m < P.M) {
       const int qw = m % P.Mw; int t = m / P.Mw;
       const int qh = t % P.Mh; t /= P.Mh;
-      const int qd = t % P.Md; const int img = t / P.Md + P.img0;
+      int qd, img;
+      if (SK && a.dmajor > 0) { img = t % a.dmajor; qd = t / a.dmajor; }    // depth-major rows: a tile sees few depth planes
+      else { qd = t % P.Md; img = t / P.Md + P.img0; }
       base = img * a.gsN;
       bd = qd * a.G.Sd + P.Od; bh = qh * a.G.Sh + P.Oh; bw = qw * a.G.Sw + P.Ow;
       oo = (((img * a.G.Xd + qd * a.G.OSd + P.Pd) * a.G.Xh + qh * a.G.OSh + P.Ph) * a.G.Xw + qw * a.G.OSw + P.Pw) *
            Ncols;
+      if (SK) {
+        int md = 0, mh = 0, mw = 0;
+        for (int j = 0; j < P.Td; ++j) md |= ((unsigned)(bd + a.G.J * j) < (unsigned)a.G.Gd ? 1 : 0) << j;
+        for (int j = 0; j < P.Th; ++j) mh |= ((unsigned)(bh + a.G.J * j) < (unsigned)a.G.Gh ? 1 : 0) << j;
+        for (int j = 0; j < P.Tw; ++j) mw |= ((unsigned)(bw + a.G.J * j) < (unsigned)a.G.Gw ? 1 : 0) << j;
+        atomicOr(&tapmask[0], md); atomicOr(&tapmask[1], mh); atomicOr(&tapmask[2], mw);
+      }
     }
     rowinfo[r * 4 + 0] = base; rowinfo[r * 4 + 1] = bd; rowinfo[r * 4 + 2] = bh; rowinfo[r * 4 + 3] = bw;
     outoff[r] = oo;
   }
   __syncthreads();
+  if (SK) {
+    // the taps some row of this tile can use, in K order (a tap is live if each of its three coordinates is in range for
+    // some row: a superset of the exact set, exact for the temporal ends this mode exists for)
+    if (tid == 0) {
+      const int tmd = tapmask[0], tmh = tapmask[1], tmw = tapmask[2];
+      int n = 0;
+      for (int t = 0; t < P.Td * P.Th * P.Tw; ++t) {
+        const int w_ = t % P.Tw, t2 = t / P.Tw, h_ = t2 % P.Th, d_ = t2 / P.Th;
+        if (((tmd >> d_) & 1) & ((tmh >> h_) & 1) & ((tmw >> w_) & 1)) taptab[n++] = t;
+      }
+      tapmask[3] = n;
+    }
+    __syncthreads();
+  }
 
   int rbase[AP], rbd[AP], rbh[AP], rbw[AP];
 #pragma unroll
@@ -333,9 +366,12 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
   // one 256-byte bank row, so a 16-lane ds_read_b128 group (rows r..r+15, same chunk) touches 16 distinct slots
   const int kchunk = GL ? (((tid & 7) ^ ((tid >> 4) & 7)) * 4) : (tid & 7) * 4;
   const int J = a.G.J, Gd = a.G.Gd, Gh = a.G.Gh, Gw = a.G.Gw;
-  const int nslab_all = P.K >> 5;
-  const int s_begin = split * a.slabs_per_split;
-  const int s_last = a.ksplit > 1 ? (s_begin + a.slabs_per_split < nslab_all ? s_begin + a.slabs_per_split : nslab_all) : nslab_all;
+  // MODE 3 walks the LIVE slabs only (and a K split shares those out evenly)
+  const int spt = Cg >> 5;         // slabs per tap
+  const int nslab_all = SK ? __builtin_amdgcn_readfirstlane(tapmask[3]) * spt : P.K >> 5;
+  const int per_split = SK ? (nslab_all + a.ksplit - 1) / a.ksplit : a.slabs_per_split;
+  const int s_begin = split * per_split;
+  const int s_last = a.ksplit > 1 ? (s_begin + per_split < nslab_all ? s_begin + per_split : nslab_all) : nslab_all;
   const int nslab = s_last > s_begin ? s_last - s_begin : 0;   // slabs of THIS workgroup
   // weight rows of this thread (clamped; rows >= Ncols are masked to zero)
   const float* wrow[BP];
@@ -344,14 +380,24 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
   for (int i = 0; i < BP; ++i) {
     const int n = nblk * BN + (tid >> 3) + RPP * i;
     wok[i] = n < Ncols;
-    wrow[i] = a.w + P.w_off + (int64_t)(wok[i] ? n : Ncols - 1) * P.Kp + kchunk + s_begin * 32;
+    wrow[i] = a.w + P.w_off + (int64_t)(wok[i] ? n : Ncols - 1) * P.Kp + kchunk + (SK ? 0 : s_begin * 32);
   }
   const bool xf = a.scale != nullptr;
   const float neg = a.act == GODE_ACT_RELU ? 0.f : (a.act == GODE_ACT_LRELU ? 0.2f : 1.f);
 
   // wave-uniform tap odometer for the slab being fetched (starts at this workgroup's first slab)
   int c0, jd, jh, jw;
-  {
+  int li = 0, wk = 0;      // MODE 3: index into the live-tap table; K offset of the odometer inside the packed panel
+  auto live_tap = [&]() {
+    const int t = __builtin_amdgcn_readfirstlane(taptab[li]);
+    jw = t % P.Tw; const int t2 = t / P.Tw; jh = t2 % P.Th; jd = t2 / P.Th;
+    wk = t * Cg;
+  };
+  if (SK) {
+    li = s_begin / spt;
+    c0 = (s_begin - li * spt) * 32;
+    if (nslab > 0) live_tap(); else { jd = jh = jw = 0; }
+  } else {
     const int k0 = s_begin * 32, tap0 = k0 / Cg;
     c0 = k0 - tap0 * Cg;
     jw = tap0 % P.Tw; const int t2 = tap0 / P.Tw; jh = t2 % P.Th; jd = t2 / P.Th;
@@ -379,7 +425,8 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
     if (c0 >= Cg) {
       c0 = 0;
       tap_dirty = true;
-      if (++jw == P.Tw) { jw = 0; if (++jh == P.Th) { jh = 0; ++jd; } }
+      if (SK) { ++li; live_tap(); }      // (one entry past the table's end is read after the last slab and never used)
+      else if (++jw == P.Tw) { jw = 0; if (++jh == P.Th) { jh = 0; ++jd; } }
     }
   };
   auto fetch = [&](int slab) {
@@ -405,7 +452,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + slab * 32),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + (SK ? wk + c0 : slab * 32)),
                                        (__attribute__((address_space(3))) void*)(dstB + RPP * i * LDK), 16, 0, 0);
     advance();
   };
@@ -1066,6 +1113,9 @@ static int launch(IgemmArgs& A, bool vec, int max_mblk, bool double_buf, const S
     const int64_t images = (int64_t)A.out_numel / ((int64_t)A.G.Xd * A.G.Xh * A.G.Xw * A.G.Ncols);
     const int64_t in_bytes = images * A.G.Gd * A.G.Gh * A.G.Gw * A.G.Cg * 4;
     int mode = ok2 ? (wbytes * 8 < 3 * in_bytes ? 3 : 0) : 0;
+    // depth-major rows with dead-tap skipping: the tiles of the end planes are light, so a contiguous run per XCD would
+    // leave the XCDs that own them idle -- interleave the m-blocks over the XCDs instead
+    if (A.dmajor > 0 && mode == 3) mode = 2;
     if (force == 0) mode = 0;
     if (force == 1 && ok1) mode = 1;
     if (force == 2 && ok2) mode = 2;
@@ -1076,7 +1126,8 @@ static int launch(IgemmArgs& A, bool vec, int max_mblk, bool double_buf, const S
     static const char* genv = getenv("GODE_IGEMM_GLDS");
     const bool glds = genv ? atoi(genv) != 0 : true;   // default; GODE_IGEMM_GLDS=0 selects register staging
     if (!has_xf && glds && !double_buf) {
-      hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 2, false>), g1, block, 0, st, A);
+      if (A.tapskip) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 3, false>), g1, block, 0, st, A);
+      else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 2, false>), g1, block, 0, st, A);
     } else if (double_buf) {
       if (has_xf) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 1, true>), g1, block, 0, st, A);
       else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 1, false>), g1, block, 0, st, A);
@@ -1125,6 +1176,19 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
   A.gsN = (int)gs[0]; A.gsD = (int)gs[1]; A.gsH = (int)gs[2]; A.gsW = (int)gs[3]; A.gsC = (int)gs[4];
   A.act = op->act; A.epilogue = op->epilogue;
   A.stagger = 0;
+  // input gradient of a convolution with temporal taps: depth-major tiles, so that the taps falling off the tensor's ends
+  // are dead for whole tiles (skipped in the FAST kernel's K loop)
+  A.dmajor = 0;
+  // (temporal stride 1: Do of the Di planes' taps land inside the tensor; below ~85 % the skipping pays for MODE 3's slower loop)
+  A.tapskip = op->dir == GODE_DGRAD && op->groups != 2 && !G.fullk && op->g.sd == 1 && G.ph[0].Td > 1 &&
+              100 * op->g.Do < 85 * op->g.Di;
+  for (int i = 0; i < G.nphase; ++i) if (G.ph[i].Td * G.ph[i].Th * G.ph[i].Tw >= IGEMM_MAX_LIVE_TAPS) A.tapskip = 0;
+  // Depth-major rows make every tile see one or two planes (a plane of >= 128 rows fills tiles by itself and keeps the
+  // image-major order, whose gather is more local).  Measured on the UCF video-D layers, N=32: 13x32x32 planes 954 ->
+  // 831 us image-major; 7x8x8 497 -> 382 us depth-major; 10x16x16 (15 MB gathered, more than an XCD's L2, and each
+  // image's tiles now spread over the whole launch) only 687 -> 672 us, but image-major with two planes per tile was 737.
+  if (A.tapskip && G.ph[0].Mh * G.ph[0].Mw < 128)
+    A.dmajor = op->g.N;
   A.stats_rows = rows;
   A.work = op->work; A.out_numel = (int32_t)outn; A.ksplit = 1; A.slabs_per_split = 0; A.MB = 0; A.NB = 0; A.xcd_mode = 0;
   if ((op->scale == nullptr) != (op->shift == nullptr)) return GODE_E_ARG;

@@ -96,6 +96,11 @@ CASES = [
     (128, 256, (10, 16, 16), (4, 4, 4), (1, 2, 2), (0, 1, 1), 16),
     (256, 512, (7, 8, 8), (4, 4, 4), (1, 2, 2), (0, 1, 1), 16),
     (512, 1, (4, 4, 4), (4, 4, 4), (1, 1, 1), (0, 0, 0), 16),
+    # their input gradients walk the live temporal taps only (FAST kernel MODE 3): few rows -> K split over the live slabs
+    # with depth-major rows; one image -> image-major tiles of whole planes
+    (256, 512, (7, 8, 8), (4, 4, 4), (1, 2, 2), (0, 1, 1), 2),
+    (64, 128, (13, 32, 32), (4, 4, 4), (1, 2, 2), (0, 1, 1), 1),
+    (128, 256, (10, 16, 16), (4, 4, 4), (1, 2, 2), (0, 1, 1), 3),
 ]
 
 
