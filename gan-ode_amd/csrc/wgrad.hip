@@ -433,6 +433,181 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(const WgradArgs a, int 
 }
 
 
+// PATCH path: first layers of the discriminators and the generator's RGB head at UCF size (Ci <= 4 but 16-64 taps, so
+// Kt = 48 / 192: too wide for the THIN path, and an im2col of a 3-channel tensor is one scalar gather per element -- the
+// generic kernel spends its time there: 17 TFLOP/s).  Here a slab is (up to) 32 consecutive positions of ONE output row;
+// the kd*kh input rows they touch are staged in LDS once, [row][w][ci] with any global strides, and the MFMA's X
+// operand is read straight out of that patch: column j = (row r, kw, ci) of position q sits at r*PL + (q*sw + kw)*Ci + ci,
+// so the per-lane part of the address is fixed and the position part is an immediate.  No im2col tile exists anywhere.
+// The padded row length PL = kw*Ci (mod 32) lets the 32 column lanes of a ds_read_b32 fall into distinct banks.
+#define WP_MAXB 4          // 32x32 output blocks per wave
+#define WP_MAXE 16         // patch elements staged per thread and slab
+struct WpArgs {
+  WgradArgs w;
+  int32_t RB, CB;          // 32-row blocks of Co, 32-column blocks of Kt
+  int32_t PR, PL, LW;      // patch rows (kd*kh), padded row length (floats), w positions per row ((32-1)*sw + kw)
+  int32_t nseg;            // 32-position segments per output row
+  FastDiv dseg;
+  int32_t segs, segs_per_wg;
+  int32_t yvec;            // y rows may be read as float4
+};
+
+#define WP_TAB 128         // slabs whose corners are decoded at a time (LDS table)
+// NBW: 32x32 output blocks per wave.  Wave w owns row block w % RB and the column blocks w / RB + (4 / RB) * k, so one
+// Y fragment serves all its MFMAs of a k step; column blocks past CB compute zeros and are not stored.  CO = Co.
+template <int NBW, int CO>
+__global__ void __launch_bounds__(256) wgrad_patch_kernel(const WpArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float wp_smem[];
+  constexpr int RB = CO / 32, CSTEP = 4 / RB, YC = CO / 4;
+  __shared__ int tab[WP_TAB][6];                     // per slab: x corner offset, bw, masks, valid positions, first y row (lo, hi)
+  const WgradArgs& a = p.w;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int Ci = a.g.Ci, Kt = a.Kt, kh = a.g.kh, kw = a.g.kw, sw = a.g.sw;
+  const int patch = p.PR * p.PL;
+  const int bufsz = patch + 32 * CO + 4;             // [patch | Y slab | dump slot of the threads without an element]
+  const int nelem = p.PR * p.LW * Ci;
+  const int ne = (nelem + 255) >> 8;                 // patch elements per thread (uniform)
+
+  // per-thread patch elements, fixed over the slabs: global offset from the slab's corner, LDS slot, and (kd, kh, local w)
+  // packed 5:5:22.  A thread past the last element gets kd = 31: never in range, its zero goes to the dump slot.
+  int e_goff[WP_MAXE], e_lds[WP_MAXE], e_key[WP_MAXE];
+#pragma unroll
+  for (int i = 0; i < WP_MAXE; ++i) {
+    const int e = tid + 256 * i;
+    const bool ok = e < nelem;
+    const int r = ok ? e / (p.LW * Ci) : 0, rem = ok ? e - r * (p.LW * Ci) : 0;
+    const int iwl = rem / Ci, ci = rem - iwl * Ci;
+    const int kdi = r / kh, khi = r - kdi * kh;
+    e_goff[i] = kdi * a.xsD + khi * a.xsH + iwl * a.xsW + ci * a.xsC;
+    e_lds[i] = ok ? r * p.PL + iwl * Ci + ci : patch + 32 * CO;
+    e_key[i] = (ok ? kdi : 31) | (khi << 5) | (iwl << 10);
+  }
+  const int rb = wave % RB;
+  int b_x[NBW], b_colj[NBW];
+  bool b_col[NBW];
+#pragma unroll
+  for (int k = 0; k < NBW; ++k) {
+    const int cb = wave / RB + CSTEP * k;
+    const int j = cb * 32 + fr;
+    b_col[k] = cb < p.CB && j < Kt;
+    const int tap = b_col[k] ? j / Ci : 0, ci = b_col[k] ? j - tap * Ci : 0;
+    const int kwi = tap % kw, r = tap / kw;
+    b_x[k] = r * p.PL + kwi * Ci + ci + fh * sw * Ci;
+    b_colj[k] = j;
+  }
+  const int y_off = patch + fh * CO + rb * 32 + fr;
+  const float yneg = a.act == GODE_ACT_RELU ? 0.f : (a.act == GODE_ACT_LRELU ? 0.2f : 1.f);
+  const bool yxf = a.scale != nullptr;               // (host: only with xform_on_y)
+  constexpr int NYC = (32 * YC + 255) / 256;         // float4 chunks of the Y slab per thread (256 % YC == 0)
+  const int yc4 = tid % YC, ypos0 = tid / YC;        // chunk i of this thread: position ypos0 + i * (256 / YC), same channels
+  f32x4 ysc = {1, 1, 1, 1}, ysh = {0, 0, 0, 0};
+  if (yxf) { ysc = *reinterpret_cast<const f32x4*>(a.scale + yc4 * 4); ysh = *reinterpret_cast<const f32x4*>(a.shift + yc4 * 4); }
+
+  f32x16 acc[NBW];
+#pragma unroll
+  for (int k = 0; k < NBW; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+  const int s0 = blockIdx.x * p.segs_per_wg;
+  const int s1 = s0 + p.segs_per_wg < p.segs ? s0 + p.segs_per_wg : p.segs;
+  float rx[WP_MAXE];
+  f32x4 ry[NYC];
+  auto fetch = [&](int t) {                          // t: slot of the slab in the table
+    const int base = __builtin_amdgcn_readfirstlane(tab[t][0]), bw = __builtin_amdgcn_readfirstlane(tab[t][1]);
+    const unsigned masks = __builtin_amdgcn_readfirstlane(tab[t][2]);     // depth taps in range | row taps in range << 5
+    const int npos = __builtin_amdgcn_readfirstlane(tab[t][3]);
+    const int64_t m0 = ((int64_t)__builtin_amdgcn_readfirstlane(tab[t][5]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(tab[t][4]);
+#pragma unroll
+    for (int i = 0; i < WP_MAXE; ++i) {
+      if (i < ne) {                                  // uniform
+        const unsigned key = (unsigned)e_key[i];
+        const bool ok = ((masks >> (key & 31)) & (masks >> (5 + ((key >> 5) & 31))) & 1u) && (unsigned)(bw + (int)(key >> 10)) < (unsigned)a.g.Wi;
+        const float v = a.x[ok ? base + e_goff[i] : 0];      // unconditional load, clamped address
+        rx[i] = ok ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NYC; ++i) {
+      const int pos = ypos0 + i * (256 / YC);
+      const bool ok = pos < npos;
+      const float* src = a.y + (m0 + (ok ? pos : 0)) * CO + yc4 * 4;
+      f32x4 v;
+      if (p.yvec) v = *reinterpret_cast<const f32x4*>(src);
+      else { v[0] = src[0]; v[1] = src[1]; v[2] = src[2]; v[3] = src[3]; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t2 = v[e];
+        if (yxf) { t2 = t2 * ysc[e] + ysh[e]; t2 = fmaxf(t2, t2 * yneg); }
+        v[e] = ok ? t2 : 0.f;
+      }
+      ry[i] = v;
+    }
+  };
+  auto stage = [&](int buf) {
+    float* P = wp_smem + buf * bufsz;
+#pragma unroll
+    for (int i = 0; i < WP_MAXE; ++i) if (i < ne) P[e_lds[i]] = rx[i];
+#pragma unroll
+    for (int i = 0; i < NYC; ++i)
+      if (ypos0 + i * (256 / YC) < 32) *reinterpret_cast<f32x4*>(P + patch + (tid + 256 * i) * 4) = ry[i];
+  };
+
+  const int qstep = 2 * sw * Ci;
+  int parity = 0;
+  for (int c0 = s0; c0 < s1; c0 += WP_TAB) {         // chunks of WP_TAB slabs
+    const int cn = s1 - c0 < WP_TAB ? s1 - c0 : WP_TAB;
+    __syncthreads();                                 // (the previous chunk's table and LDS buffers are no longer read)
+    if (tid < cn) {
+      const uint32_t sidx = c0 + tid;
+      const uint32_t orow = fdiv(sidx, p.dseg), seg = sidx - orow * p.nseg;
+      const uint32_t t1 = fdiv(orow, a.dHo), qh = orow - t1 * a.g.Ho;
+      const uint32_t img = fdiv(t1, a.dDo), qd = t1 - img * a.g.Do;
+      const int qw0 = (int)seg * 32;
+      const int bd = (int)qd * a.g.sd - a.g.pd, bh = (int)qh * a.g.sh - a.g.ph, bw = qw0 * sw - a.g.pw;
+      unsigned masks = 0;
+      for (int k = 0; k < a.g.kd; ++k) masks |= ((unsigned)(bd + k) < (unsigned)a.g.Di ? 1u : 0u) << k;
+      for (int k = 0; k < kh; ++k) masks |= ((unsigned)(bh + k) < (unsigned)a.g.Hi ? 1u : 0u) << (5 + k);
+      const int64_t m0 = (int64_t)orow * a.g.Wo + qw0;
+      tab[tid][0] = (int)img * a.xsN + bd * a.xsD + bh * a.xsH + bw * a.xsW;
+      tab[tid][1] = bw; tab[tid][2] = (int)masks;
+      tab[tid][3] = a.g.Wo - qw0 < 32 ? a.g.Wo - qw0 : 32;
+      tab[tid][4] = (int)(uint32_t)m0; tab[tid][5] = (int)(m0 >> 32);
+    }
+    __syncthreads();
+    fetch(0); stage(parity);
+    __syncthreads();
+    for (int t = 0; t < cn; ++t) {
+      const int buf = parity;
+      if (t + 1 < cn) fetch(t + 1);
+      const float* P = wp_smem + buf * bufsz;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const float av = P[y_off + ks * 2 * CO];
+#pragma unroll
+        for (int k = 0; k < NBW; ++k) {
+          const float xv = P[b_x[k] + ks * qstep];
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_col[k] ? xv : 0.f, acc[k], 0, 0, 0);
+        }
+      }
+      if (t + 1 < cn) stage(buf ^ 1);
+      parity ^= 1;
+      __syncthreads();
+    }
+  }
+
+  float* dst = a.work + (int64_t)blockIdx.x * CO * Kt;
+#pragma unroll
+  for (int k = 0; k < NBW; ++k) {
+    if (b_col[k]) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        dst[(int64_t)(rb * 32 + 4 * fh + (r & 3) + 8 * (r >> 2)) * Kt + b_colj[k]] = acc[k][r];
+    }
+  }
+}
+
 // sums the split-K slabs in fixed order (fp64 running sum) and scatters into the canonical layout; VEC4: four
 // consecutive (co, j) entries per thread with float4 slab reads (Kt % 4 == 0)
 template <bool VEC4>
@@ -535,7 +710,39 @@ static int wg_thin_blocks(const gode_conv_geom& g) {
   int64_t b = (M + 63) / 64;       // ~4 positions per thread (the per-position gather chain is serial), up to 1024 workgroups
   return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
 }
+// PATCH path eligibility and launch shape (a function of the op's geometry and transform only, so that the work-size
+// query and the launch agree)
+static bool wg_patch(const gode_wgrad_op* op, WpArgs* P) {
+  const gode_conv_geom& g = op->g;
+  const int Kt = g.kd * g.kh * g.kw * g.Ci;
+  if (op->splits > 0 || g.Ci > 4 || Kt <= THIN_MAXKT || (g.Co != 32 && g.Co != 64 && g.Co != 128) || g.Wo < 16) return false;
+  if (op->scale && !op->xform_on_y) return false;
+  const int RB = g.Co / 32, CB = (Kt + 31) / 32;
+  if ((CB + 4 / RB - 1) / (4 / RB) > WP_MAXB) return false;
+  const int PR = g.kd * g.kh, LW = 31 * g.sw + g.kw;
+  if (PR > 255 || LW > 32767 || PR * LW * g.Ci > 256 * WP_MAXE) return false;
+  int PL = LW * g.Ci;
+  while (PL % 32 != (g.kw * g.Ci) % 32) ++PL;
+  if (2 * (PR * PL + 32 * g.Co + 4) * 4 > 64 * 1024 || 256 % (g.Co / 4) != 0 || PR > 30 || g.kd > 30 || g.kh > 30) return false;
+  const int nseg = (g.Wo + 31) / 32;
+  const int64_t segs = (int64_t)g.N * g.Do * g.Ho * nseg;
+  if (segs >= (1ll << 31)) return false;
+  if (P) {
+    P->RB = RB; P->CB = CB; P->PR = PR; P->PL = PL; P->LW = LW; P->nseg = nseg; P->dseg = make_fastdiv((uint32_t)nseg); P->segs = (int)segs;
+    int wgs = (int)(segs / 8 < 1 ? 1 : segs / 8);            // >= 8 segments per workgroup, two workgroups per CU at most
+    if (wgs > 512) wgs = 512;
+    P->segs_per_wg = (int)((segs + wgs - 1) / wgs);
+  }
+  return true;
+}
+static int wg_patch_blocks(const gode_wgrad_op* op) {
+  WpArgs P;
+  if (!wg_patch(op, &P)) return 0;
+  return (P.segs + P.segs_per_wg - 1) / P.segs_per_wg;
+}
+
 static int wg_splits(const gode_wgrad_op* op) {
+  if (const int pb = wg_patch_blocks(op)) return pb;
   if (op->splits <= 0 && wg_thin(op->g)) return wg_thin_blocks(op->g);
   return op->splits > 0 ? op->splits : gode_wgrad_auto_splits(&op->g);
 }
@@ -592,7 +799,24 @@ extern "C" int gode_wgrad(const gode_wgrad_op* op, void* stream) {
   const bool vy = g.Co % 4 == 0 && (uintptr_t)op->y % 16 == 0;
   hipStream_t st = (hipStream_t)stream;
   const int t = wg_tile(g);
-  if (op->splits <= 0 && wg_thin(g) && vy) {
+  WpArgs WP;
+  const bool patch = wg_patch(op, &WP);
+  if (patch) {
+    WP.w = A;
+    WP.yvec = (uintptr_t)op->y % 16 == 0;
+    const size_t lds = (size_t)2 * (WP.PR * WP.PL + 32 * g.Co + 4) * sizeof(float);
+    const int nbw = (WP.CB + 4 / WP.RB - 1) / (4 / WP.RB);      // column blocks per wave
+    void (*kern)(const WpArgs) = nullptr;
+#define WP_PICK(N, C) if (nbw == N && g.Co == C) kern = wgrad_patch_kernel<N, C>;
+    WP_PICK(1, 32) WP_PICK(2, 32) WP_PICK(3, 32) WP_PICK(4, 32)
+    WP_PICK(1, 64) WP_PICK(2, 64) WP_PICK(3, 64) WP_PICK(4, 64)
+    WP_PICK(1, 128) WP_PICK(2, 128) WP_PICK(3, 128) WP_PICK(4, 128)
+#undef WP_PICK
+    if (!kern) return GODE_E_SHAPE;
+    hipLaunchKernelGGL(kern, dim3(splits), dim3(256), lds, st, WP);
+    GODE_LAUNCH_CHECK();
+    rc = 0;
+  } else if (op->splits <= 0 && wg_thin(g) && vy) {
     const int chunk_thin = (int)((M + splits - 1) / splits);
     hipLaunchKernelGGL(wgrad_thin_kernel, dim3(splits), dim3(256), 0, st, A, chunk_thin);
     GODE_LAUNCH_CHECK();
@@ -602,7 +826,7 @@ extern "C" int gode_wgrad(const gode_wgrad_op* op, void* stream) {
   else rc = wg_launch<2, 2, 2, 2>(A, vx, vy, splits, st);
   if (rc) return rc;
   const int64_t total = (int64_t)g.Co * A.Kt;
-  if (total <= 8192 && splits >= 16) {
+  if ((total <= 8192 || (patch && total <= 32768)) && splits >= 16) {   // (patch path: hundreds of slabs of a [Co][Kt] of a few thousand)
     hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((int)((total + RS_OUT - 1) / RS_OUT)), dim3(256), 0, st, op->work, op->dw, g.Co,
                        g.Ci, A.taps, splits, op->co_perm, op->accumulate);
     GODE_LAUNCH_CHECK();

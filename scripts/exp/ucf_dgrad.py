@@ -39,3 +39,27 @@ run("dec L1 convT 512->256 fwd", make_geom(512, 256, 512, (1, 8, 8), (1, 4, 4), 
 run("dec L3 convT 128->64 fwd", make_geom(512, 64, 128, (1, 32, 32), (1, 16, 16), (1, 4, 4), (1, 2, 2), (0, 1, 1)), L.DGRAD)
 run("dec L3 bwd (fprop)", make_geom(512, 64, 128, (1, 32, 32), (1, 16, 16), (1, 4, 4), (1, 2, 2), (0, 1, 1)), L.FPROP)
 run("mnist dv L2 dgrad N=64", make_geom(64, 128, 256, (14, 8, 8), (13, 5, 5), (2, 2, 2), (1, 2, 2), (0, 1, 1)), L.DGRAD)
+
+def run_wgrad(name, g, on_y=False, strided=False):
+    if strided:   # [N, D, C, H, W] memory (the real-video tensor), logical strides N, D, H, W, C
+        xm = torch.randn(g.N, g.Di, g.Ci, g.Hi, g.Wi, device="cuda")
+        xs = (xm.stride(0), xm.stride(1), xm.stride(3), xm.stride(4), xm.stride(2))
+    else:
+        xm = torch.randn(g.N, g.Di, g.Hi, g.Wi, g.Ci, device="cuda"); xs = None
+    y = torch.randn(g.N, g.Do, g.Ho, g.Wo, g.Co, device="cuda")
+    dw = torch.empty(g.Co, g.Ci, g.kd, g.kh, g.kw, device="cuda")
+    sc, sh = torch.rand(g.Co, device="cuda") + 0.5, torch.randn(g.Co, device="cuda")
+    op = L.WgradOp(g=g, act=L.ACT_RELU if on_y else L.ACT_NONE, xform_on_y=1 if on_y else 0, splits=0, accumulate=0, x=xm.data_ptr(), y=y.data_ptr(),
+                   scale=sc.data_ptr() if on_y else None, shift=sh.data_ptr() if on_y else None, dw=dw.data_ptr())
+    if xs:
+        for i in range(5): op.xs[i] = xs[i]
+    work = torch.empty(lib.gode_wgrad_work_size(C.byref(op)), device="cuda")
+    op.work = work.data_ptr()
+    flop = 2.0 * g.N * g.Do * g.Ho * g.Wo * g.Co * g.Ci * g.kd * g.kh * g.kw
+    ms = timeit(op)
+    print(f"{name:40s} {ms*1e3:9.1f} us {flop/ms/1e9:7.1f} TF", flush=True)
+
+run_wgrad("ucf dv L0 wgrad N=16 (channels-last)", make_geom(16, 3, 64, (16, 64, 64), (13, 32, 32), (4, 4, 4), (1, 2, 2), (0, 1, 1)))
+run_wgrad("ucf dv L0 wgrad N=16 (NDCHW video)", make_geom(16, 3, 64, (16, 64, 64), (13, 32, 32), (4, 4, 4), (1, 2, 2), (0, 1, 1)), strided=True)
+run_wgrad("ucf G head wgrad N=256", make_geom(256, 3, 64, (1, 64, 64), (1, 32, 32), (1, 4, 4), (1, 2, 2), (0, 1, 1)), on_y=True)
+run_wgrad("ucf di L0 wgrad N=16", make_geom(16, 3, 64, (1, 64, 64), (1, 32, 32), (1, 4, 4), (1, 2, 2), (0, 1, 1)))
