@@ -1,5 +1,5 @@
 """Per-op table of one training iteration (L.TRACE: every libgode op between two stream events): kind, geometry, us,
-TFLOP/s.  python scripts/iter_ops.py [mnist|ucf] > gpurun_out/iter_ops.txt"""
+TFLOP/s.  python scripts/iter_ops.py [mnist|ucf|odernn] > gpurun_out/iter_ops.txt"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,6 +12,8 @@ G.limit_host_threads()
 torch.manual_seed(0); np.random.seed(0)
 if cfg == "ucf":
     gen, dv, di = G.build_ucf(); B, C_, HW = 16, 3, 64
+elif cfg == "odernn":
+    _, dv, di = G.build_mnist(); gen = G.VideoGeneratorMNISTODERNN(1, 50, 0, 16, 16); B, C_, HW = 32, 1, 28
 else:
     gen, dv, di = G.build_mnist(); B, C_, HW = 32, 1, 28
 gen.cuda(); dv.cuda(); di.cuda()
@@ -32,7 +34,7 @@ for rep in range(reps):
     for i, (op, e0, e1) in enumerate(trace):
         acc.setdefault(i, [op, 0.0])[1] += e0.elapsed_time(e1) * 1e3 / reps
 rows = []
-names = {1: "igemm", 2: "wgrad", 3: "bn_fin", 4: "bn_bwd", 5: "ode_fwd", 6: "ode_bwd", 7: "bce", 8: "adam", 9: "pack", 12: "bn_apply"}
+names = {1: "igemm", 2: "wgrad", 3: "bn_fin", 4: "bn_bwd", 5: "ode_fwd", 6: "ode_bwd", 7: "bce", 8: "adam", 9: "pack", 10: "odernn_fwd", 11: "odernn_bwd", 12: "bn_apply"}
 tot = 0.0
 for i in sorted(acc):
     op, us = acc[i]
@@ -48,7 +50,7 @@ for i in sorted(acc):
                 desc += f" xf={'y' if op.scale else 'n'} act={op.act} stats={'y' if op.stats else 'n'}"
         elif op.KIND in (3, 4, 12):
             desc += f" C={op.C} M={getattr(op, 'M', getattr(op, 'count', 0))}"
-        elif op.KIND in (5, 6):
+        elif op.KIND in (5, 6, 10, 11):
             desc += f" N={op.N} T={op.T}"
     tot += us
     rows.append((i, us, fl, desc))
