@@ -101,6 +101,11 @@ CASES = [
     (256, 512, (7, 8, 8), (4, 4, 4), (1, 2, 2), (0, 1, 1), 2),
     (64, 128, (13, 32, 32), (4, 4, 4), (1, 2, 2), (0, 1, 1), 1),
     (128, 256, (10, 16, 16), (4, 4, 4), (1, 2, 2), (0, 1, 1), 3),
+    # weight gradients through the LDS-patch kernel (few input channels, many taps): a short output row (one partial
+    # 32-position segment), a row of one and a half segments with Co = 128, and Co = 32 with a depth tap
+    (3, 32, (1, 40, 40), (1, 4, 4), (1, 2, 2), (0, 1, 1), 3),
+    (2, 128, (2, 20, 96), (2, 3, 3), (1, 1, 2), (0, 1, 1), 2),
+    (4, 32, (5, 18, 66), (3, 3, 3), (1, 2, 2), (1, 0, 1), 2),
 ]
 
 
