@@ -971,6 +971,15 @@ static int pick_tile_split_aware(const gode_conv_geom& g, const IgemmGeom& G, in
 // (two or more resident workgroups per CU overlap each other's barriers; a lone one cannot) and ~4k cycles of
 // prologue + epilogue.  Checked against measurements: ConvT 128->64 (4096 x 128x64) 314 us model / 297 us measured;
 // UCF video-D layer-2 dgrad 128x128 578 / 514 us, for which the model prefers 128x64 (436 us).
+// MODE 3 of the FAST kernel (live taps only) pays for its slower loop when the temporal taps that fall off the tensor's
+// ends are > 15 % of the K loop (temporal stride 1: Do of the Di planes' taps are live)
+static bool igemm_wants_tapskip(const gode_igemm_op* op, const IgemmGeom& G) {
+  if (!(op->dir == GODE_DGRAD && op->groups != 2 && !G.fullk && op->g.sd == 1 && G.ph[0].Td > 1 && 100 * op->g.Do < 85 * op->g.Di))
+    return false;
+  for (int i = 0; i < G.nphase; ++i) if (G.ph[i].Td * G.ph[i].Th * G.ph[i].Tw >= IGEMM_MAX_LIVE_TAPS) return false;
+  return true;
+}
+
 static void choose_fast(const gode_igemm_op* op, const IgemmGeom& G, int* tile_out, SplitPlan* sp_out) {
   const gode_conv_geom& g = op->g;
   const int positions = g.N * G.Xd * G.Xh * G.Xw;
@@ -985,6 +994,7 @@ static void choose_fast(const gode_igemm_op* op, const IgemmGeom& G, int* tile_o
   }
   static const int tiles[4] = {TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32};
   static const int ksplits[10] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+  const bool live_taps = igemm_wants_tapskip(op, G);
   double best = 1e300;
   int best_tile = G.Ncols <= 32 ? TILE_128x32 : TILE_128x64, best_k = 1;
   for (int ti = 0; ti < 4; ++ti) {
@@ -1000,10 +1010,14 @@ static void choose_fast(const gode_igemm_op* op, const IgemmGeom& G, int* tile_o
       const int k = ksplits[ki];
       if (k > 1 && (min_slabs / k < 4 || out_bytes * k > 192e6 || min_slabs != max_slabs || !even_phases)) break;
       const int64_t blocks = tiles_n * k;
-      const int64_t per_cu = (blocks + 255) / 256;
+      // live-tap launches: tiles of the end planes are short, so the hardware's in-order dispatch evens the CUs out and
+      // the whole-rounds quantisation does not apply to the big tile (measured, UCF video-D layer 2 input gradient at
+      // N=32, 640 tiles of 128x128 vs 1280 of 128x64: 600 vs 670 us although 640 is 2.5 rounds; at N=16 the smaller
+      // tile with a K split stays ahead, 370 vs 388 us)
+      const double per_cu = (live_taps && t == TILE_128x128 && k == 1 && blocks >= 512) ? blocks / 256.0 : (double)((blocks + 255) / 256);
       const int slabs = gode_ceil_div(max_slabs, k);
       const double eff = (per_cu >= 2 && resident >= 2) ? eff2 : 0.8 * eff2;
-      double cyc = (double)per_cu * (4000.0 + slabs * cps / eff);
+      double cyc = per_cu * (4000.0 + slabs * cps / eff);
       if (k > 1) cyc += 2.4e9 * (2.5e-6 + (k + 1) * out_bytes / 3e12);
       if (cyc < best * 0.97) { best = cyc; best_tile = t; best_k = k; }   // 3 % hysteresis toward the earlier (larger) choice
     }
@@ -1179,15 +1193,12 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
   // input gradient of a convolution with temporal taps: depth-major tiles, so that the taps falling off the tensor's ends
   // are dead for whole tiles (skipped in the FAST kernel's K loop)
   A.dmajor = 0;
-  // (temporal stride 1: Do of the Di planes' taps land inside the tensor; below ~85 % the skipping pays for MODE 3's slower loop)
-  A.tapskip = op->dir == GODE_DGRAD && op->groups != 2 && !G.fullk && op->g.sd == 1 && G.ph[0].Td > 1 &&
-              100 * op->g.Do < 85 * op->g.Di;
-  for (int i = 0; i < G.nphase; ++i) if (G.ph[i].Td * G.ph[i].Th * G.ph[i].Tw >= IGEMM_MAX_LIVE_TAPS) A.tapskip = 0;
+  A.tapskip = igemm_wants_tapskip(op, G);
   // Depth-major rows make every tile see one or two planes (a plane of >= 128 rows fills tiles by itself and keeps the
   // image-major order, whose gather is more local).  Measured on the UCF video-D layers, N=32: 13x32x32 planes 954 ->
   // 831 us image-major; 7x8x8 497 -> 382 us depth-major; 10x16x16 (15 MB gathered, more than an XCD's L2, and each
   // image's tiles now spread over the whole launch) only 687 -> 672 us, but image-major with two planes per tile was 737.
-  if (A.tapskip && G.ph[0].Mh * G.ph[0].Mw < 128)
+  if (A.tapskip && G.ph[0].Mh * G.ph[0].Mw < tile_bm(tile))
     A.dmajor = op->g.N;
   A.stats_rows = rows;
   A.work = op->work; A.out_numel = (int32_t)outn; A.ksplit = 1; A.slabs_per_split = 0; A.MB = 0; A.NB = 0; A.xcd_mode = 0;
