@@ -715,6 +715,7 @@ static int wg_thin_blocks(const gode_conv_geom& g) {
 static bool wg_patch(const gode_wgrad_op* op, WpArgs* P) {
   const gode_conv_geom& g = op->g;
   const int Kt = g.kd * g.kh * g.kw * g.Ci;
+  // (Kt <= 16 stays on the THIN path: measured on the MNIST first layers, 33 / 36 us there against 44 / 84 us here)
   if (op->splits > 0 || g.Ci > 4 || Kt <= THIN_MAXKT || (g.Co != 32 && g.Co != 64 && g.Co != 128) || g.Wo < 16) return false;
   if (op->scale && !op->xform_on_y) return false;
   const int RB = g.Co / 32, CB = (Kt + 31) / 32;

@@ -63,3 +63,6 @@ run_wgrad("ucf dv L0 wgrad N=16 (channels-last)", make_geom(16, 3, 64, (16, 64, 
 run_wgrad("ucf dv L0 wgrad N=16 (NDCHW video)", make_geom(16, 3, 64, (16, 64, 64), (13, 32, 32), (4, 4, 4), (1, 2, 2), (0, 1, 1)), strided=True)
 run_wgrad("ucf G head wgrad N=256", make_geom(256, 3, 64, (1, 64, 64), (1, 32, 32), (1, 4, 4), (1, 2, 2), (0, 1, 1)), on_y=True)
 run_wgrad("ucf di L0 wgrad N=16", make_geom(16, 3, 64, (1, 64, 64), (1, 32, 32), (1, 4, 4), (1, 2, 2), (0, 1, 1)))
+run_wgrad("mnist dv L0 wgrad N=32", make_geom(32, 1, 64, (16, 28, 28), (15, 15, 15), (2, 2, 2), (1, 2, 2), (0, 1, 1)), strided=True)
+run_wgrad("mnist di L0 wgrad N=32", make_geom(32, 1, 64, (1, 28, 28), (1, 14, 14), (1, 4, 4), (1, 2, 2), (0, 1, 1)))
+run_wgrad("mnist G head wgrad N=512", make_geom(512, 1, 64, (1, 28, 28), (1, 32, 32), (1, 1, 1), (1, 1, 1), (0, 2, 2)), on_y=True)
