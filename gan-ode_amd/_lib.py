@@ -14,7 +14,7 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH_OUT = 0, 1, 2, 3
 EPI_RAW, EPI_TANH = 0, 1
 FPROP, DGRAD = 0, 1
 OP_IGEMM, OP_WGRAD, OP_BN_FINALIZE, OP_BN_BWD, OP_ODE_FWD, OP_ODE_BWD, OP_BCE, OP_ADAM, OP_PACK = range(1, 10)
-OP_ODERNN_FWD, OP_ODERNN_BWD, OP_BN_APPLY = 10, 11, 12
+OP_ODERNN_FWD, OP_ODERNN_BWD, OP_BN_APPLY, OP_COL2IM = 10, 11, 12, 13
 ODE_NPARAM = 2672
 ODERNN_NPARAM = 2176
 
@@ -99,6 +99,11 @@ class BnApplyOp(C.Structure):
     KIND = OP_BN_APPLY
 
 
+class Col2imOp(C.Structure):
+    _fields_ = [("cols", ptr), ("out", ptr)] + [(n, i32) for n in "N Hi Wi Ho Wo C kh kw sh sw ph pw epilogue pad_".split()]
+    KIND = OP_COL2IM
+
+
 class BceOp(C.Structure):
     _fields_ = [("logits", ptr), ("grad", ptr), ("loss", ptr), ("n", i64), ("target", f32), ("gscale", f32),
                 ("accumulate", i32), ("pad_", i32)]
@@ -118,11 +123,11 @@ class PackOp(C.Structure):
 
 _STRUCTS = {0: ConvGeom, OP_IGEMM: IgemmOp, OP_WGRAD: WgradOp, OP_BN_FINALIZE: BnFinalizeOp, OP_BN_BWD: BnBwdOp,
             OP_ODE_FWD: OdeFwdOp, OP_ODE_BWD: OdeBwdOp, OP_BCE: BceOp, OP_ADAM: AdamOp, OP_PACK: PackOp,
-            OP_ODERNN_FWD: OdeRnnFwdOp, OP_ODERNN_BWD: OdeRnnBwdOp, OP_BN_APPLY: BnApplyOp}
+            OP_ODERNN_FWD: OdeRnnFwdOp, OP_ODERNN_BWD: OdeRnnBwdOp, OP_BN_APPLY: BnApplyOp, OP_COL2IM: Col2imOp}
 
 EXPORTS = ["gode_igemm", "gode_igemm_stats_rows", "gode_igemm_stats_rows0", "gode_igemm_work_size", "gode_pack_size", "gode_pack_weights", "gode_wgrad",
            "gode_wgrad_work_size", "gode_wgrad_auto_splits", "gode_bn_finalize", "gode_bn_bwd",
-           "gode_bn_bwd_work_size", "gode_bn_apply", "gode_ode_fwd", "gode_ode_bwd", "gode_ode_bwd_work_size", "gode_odernn_fwd",
+           "gode_bn_bwd_work_size", "gode_bn_apply", "gode_col2im", "gode_ode_fwd", "gode_ode_bwd", "gode_ode_bwd_work_size", "gode_odernn_fwd",
            "gode_odernn_bwd", "gode_odernn_bwd_work_size", "gode_bce_logits",
            "gode_adam_l2", "gode_adam_multi", "gode_adam_multi_dev", "gode_scale", "gode_run", "gode_version", "gode_sizeof"]
 
@@ -146,7 +151,7 @@ def lib():
         if L.gode_sizeof(kind) != C.sizeof(st):
             raise RuntimeError(f"ABI mismatch for op kind {kind}: C {L.gode_sizeof(kind)} != ctypes {C.sizeof(st)}")
     for name in ("gode_igemm", "gode_wgrad", "gode_bn_finalize", "gode_bn_bwd", "gode_ode_fwd", "gode_ode_bwd",
-                 "gode_bce_logits", "gode_adam_l2", "gode_odernn_fwd", "gode_odernn_bwd", "gode_bn_apply"):
+                 "gode_bce_logits", "gode_adam_l2", "gode_odernn_fwd", "gode_odernn_bwd", "gode_bn_apply", "gode_col2im"):
         getattr(L, name).argtypes = [ptr, ptr]
         getattr(L, name).restype = C.c_int
     L.gode_igemm_stats_rows.argtypes = [ptr]
@@ -232,5 +237,5 @@ def _run_one(op, stream):
     fn = {OP_IGEMM: "gode_igemm", OP_WGRAD: "gode_wgrad", OP_BN_FINALIZE: "gode_bn_finalize", OP_BN_BWD: "gode_bn_bwd",
           OP_ODE_FWD: "gode_ode_fwd", OP_ODE_BWD: "gode_ode_bwd", OP_BCE: "gode_bce_logits",
           OP_ADAM: "gode_adam_l2", OP_ODERNN_FWD: "gode_odernn_fwd", OP_ODERNN_BWD: "gode_odernn_bwd",
-          OP_BN_APPLY: "gode_bn_apply"}[op.KIND]
+          OP_BN_APPLY: "gode_bn_apply", OP_COL2IM: "gode_col2im"}[op.KIND]
     check(getattr(lib(), fn)(C.byref(op), stream), fn)

@@ -18,6 +18,7 @@ extern "C" int gode_sizeof(int kind) {
     case GODE_OP_ODERNN_FWD: return (int)sizeof(gode_odernn_fwd_op);
     case GODE_OP_ODERNN_BWD: return (int)sizeof(gode_odernn_bwd_op);
     case GODE_OP_BN_APPLY: return (int)sizeof(gode_bn_apply_op);
+    case GODE_OP_COL2IM: return (int)sizeof(gode_col2im_op);
   }
   return GODE_E_KIND;
 }
@@ -42,6 +43,7 @@ extern "C" int gode_run(const int32_t* kinds, const void* const* ops, int32_t n,
       case GODE_OP_ODERNN_FWD: rc = gode_odernn_fwd((const gode_odernn_fwd_op*)ops[i], stream); break;
       case GODE_OP_ODERNN_BWD: rc = gode_odernn_bwd((const gode_odernn_bwd_op*)ops[i], stream); break;
       case GODE_OP_BN_APPLY: rc = gode_bn_apply((const gode_bn_apply_op*)ops[i], stream); break;
+      case GODE_OP_COL2IM: rc = gode_col2im((const gode_col2im_op*)ops[i], stream); break;
       case GODE_OP_PACK: {
         // every run of consecutive pack ops goes out as one launch per 8 panels
         int j = i;

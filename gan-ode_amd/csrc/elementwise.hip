@@ -101,6 +101,43 @@ extern "C" int gode_bn_apply(const gode_bn_apply_op* op, void* stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// col2im of a thin-output transposed convolution (see gode_col2im_op): one thread per output pixel, <= ceil(kh/sh) *
+// ceil(kw/sw) taps of C floats each; every element of cols is read exactly once per launch.
+__global__ void __launch_bounds__(256) col2im_kernel(const gode_col2im_op a) {
+  const int64_t total = (int64_t)a.N * a.Ho * a.Wo;
+  const int KC = a.kh * a.kw * a.C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ow = (int)(i % a.Wo); const int64_t t = i / a.Wo;
+    const int oh = (int)(t % a.Ho), n = (int)(t / a.Ho);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int kh = (oh + a.ph) % a.sh; kh < a.kh; kh += a.sh) {
+      const int ih = (oh + a.ph - kh) / a.sh;
+      if (oh + a.ph - kh < 0 || ih >= a.Hi) continue;
+      for (int kw = (ow + a.pw) % a.sw; kw < a.kw; kw += a.sw) {
+        const int iw = (ow + a.pw - kw) / a.sw;
+        if (ow + a.pw - kw < 0 || iw >= a.Wi) continue;
+        const float* src = a.cols + ((int64_t)(n * a.Hi + ih) * a.Wi + iw) * KC + (kh * a.kw + kw) * a.C;
+        for (int c = 0; c < a.C; ++c) acc[c] += src[c];
+      }
+    }
+    float* dst = a.out + i * a.C;
+    for (int c = 0; c < a.C; ++c) dst[c] = a.epilogue == GODE_EPI_TANH ? tanhf(acc[c]) : acc[c];
+  }
+}
+
+extern "C" int gode_col2im(const gode_col2im_op* op, void* stream) {
+  if (!op || !op->cols || !op->out || op->N <= 0 || op->C <= 0 || op->C > 4 || op->kh <= 0 || op->kw <= 0 || op->sh <= 0 ||
+      op->sw <= 0 || op->ph < 0 || op->pw < 0 || op->Hi <= 0 || op->Wi <= 0)
+    return GODE_E_ARG;
+  if (op->Ho != (op->Hi - 1) * op->sh - 2 * op->ph + op->kh || op->Wo != (op->Wi - 1) * op->sw - 2 * op->pw + op->kw) return GODE_E_SHAPE;
+  if (op->epilogue != GODE_EPI_RAW && op->epilogue != GODE_EPI_TANH) return GODE_E_ARG;
+  int64_t nb = ((int64_t)op->N * op->Ho * op->Wo + 255) / 256; if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(col2im_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, *op);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // BatchNorm + activation backward
 #define BNB_ROWS 256   // rows per reduction block
 #define BNB_CL 16      // float4 channel lanes per block (64 channels)

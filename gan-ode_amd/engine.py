@@ -194,6 +194,20 @@ class ConvStack:
         macs = g.N * g.Do * g.Ho * g.Wo * g.Co * g.Ci * taps
         return C_out % 32 == 0 and macs >= (1 << 30) and (prod.has_bn or prod.act != L.ACT_NONE)
 
+    def _head_as_gemm(self, l):
+        """A thin-output ConvTranspose2d at the end of the stack (<= 4 output channels, > 1 tap, many pixels: the UCF
+        generator's RGB head) runs as one plain GEMM over the input pixels + an overlap-add pass (gode_col2im):
+        every input activation is read once instead of once per tap and phase.  Returns the GEMM's geometry or None."""
+        s = self.specs[l]
+        g = s.geom
+        taps = g.kh * g.kw
+        pixels = g.N * g.Ho * g.Wo
+        if (l != self.nl - 1 or self.groups != 1 or s.fwd_dir != L.DGRAD or s.has_bn or g.kd != 1 or g.Di != 1 or g.Do != 1
+                or g.Ci > 4 or taps == 1 or taps * g.Ci <= 4 or g.Co % 32 != 0 or pixels < 16384
+                or (g.Ho == 1 and g.Wo == 1) or s.epilogue not in (L.EPI_RAW, L.EPI_TANH)):
+            return None
+        return make_geom(pixels, g.Ci, g.Co, (1, g.kh, g.kw), (1, 1, 1), (1, g.kh, g.kw), (1, 1, 1), (0, 0, 0))
+
     def _in_src(self, l):
         """Tensor the consumer layer l reads (activated copy if materialised, else the raw producer output)."""
         if l == 0:
@@ -267,6 +281,24 @@ class ConvStack:
                     d = s.out_dims()
                     ops.append(L.BnApplyOp(y=dptr(self.y[0]), out=dptr(self.a[0]), scale=None, shift=None,
                                            M=d[0] * d[1] * d[2] * d[3], C=d[4], act=s.act))
+                continue
+            hg = self._head_as_gemm(l)
+            if hg is not None:
+                n = lib.gode_pack_size(C.byref(hg), L.DGRAD)
+                wp = self._shared_pack(l, "head_gemm", n)
+                packs.append((l, "head_gemm", L.PackOp(g=hg, dir=L.DGRAD, co_canon=0, w=dptr(p.weight), wpack=dptr(wp),
+                                                       co_perm=dptr(s.co_perm))))
+                g = s.geom
+                if getattr(self, "_head_cols", None) is None:
+                    self._head_cols = torch.empty(hg.N * g.kh * g.kw * g.Ci, dtype=torch.float32, device=self.device)
+                ops.append(L.IgemmOp(g=hg, dir=L.DGRAD, act=act, epilogue=L.EPI_RAW, tile=0, src=dptr(src), wpack=dptr(wp),
+                                     out=dptr(self._head_cols), scale=dptr(sc), shift=dptr(sh)))
+                c2i = L.Col2imOp(cols=dptr(self._head_cols), out=None, N=g.N, Hi=g.Ho, Wi=g.Wo, Ho=g.Hi, Wo=g.Wi, C=g.Ci,
+                                 kh=g.kh, kw=g.kw, sh=g.sh, sw=g.sw, ph=g.ph, pw=g.pw, epilogue=s.epilogue)
+                ops.append(c2i)
+                patch["last"] = c2i
+                if l == 0:
+                    raise RuntimeError("a one-layer stack cannot use the GEMM + col2im head")
                 continue
             want_stats = s.has_bn and training
             op = L.IgemmOp(g=s.geom, dir=s.fwd_dir, act=act, epilogue=s.epilogue, tile=0, src=dptr(src),

@@ -129,6 +129,18 @@ typedef struct gode_bn_apply_op {
 } gode_bn_apply_op;
 int gode_bn_apply(const gode_bn_apply_op* op, void* stream);
 
+/* Overlap-add of per-pixel tap contributions: the second half of a thin-output ConvTranspose2d (the UCF generator's
+ * RGB head, models/mocogan.py:213) computed as ONE plain GEMM over the input pixels -- gode_igemm, DGRAD of the geometry
+ * {N = pixels, Di x Hi x Wi = 1 x kh x kw, Do = Ho = Wo = 1}: cols[pixel][(kh, kw, c)] -- followed by
+ *   out[n][oh][ow][c] = epilogue( sum over taps with oh = ih*sh - ph + kh, ow = iw*sw - pw + kw of cols[(n, ih, iw)][(kh, kw, c)] )
+ * in fixed tap order.  Every input activation is then read once instead of once per tap and phase. */
+typedef struct gode_col2im_op {
+  const float* cols; float* out;
+  int32_t N, Hi, Wi, Ho, Wo, C, kh, kw, sh, sw, ph, pw;   /* Hi x Wi: the pixels of cols; Ho x Wo: out */
+  int32_t epilogue, pad_;                                  /* GODE_EPI_RAW / GODE_EPI_TANH */
+} gode_col2im_op;
+int gode_col2im(const gode_col2im_op* op, void* stream);
+
 /* backward of y -> BN -> act given g_a = dL/d(act output), all [M][C] channels-last:
  *   g_z = g_a * act'(scale*y+shift);  dbeta = sum g_z;  dgamma = sum g_z*xhat;
  *   g_y = gamma*invstd*(g_z - dbeta/M - xhat*dgamma/M)     written in place over g_a.
@@ -260,7 +272,7 @@ int gode_scale(float* out, const float* a, int64_t n, float alpha, int accumulat
 /* ---- program runner: executes n ops back to back on the stream (one host call per network pass) -------------*/
 enum { GODE_OP_IGEMM = 1, GODE_OP_WGRAD = 2, GODE_OP_BN_FINALIZE = 3, GODE_OP_BN_BWD = 4, GODE_OP_ODE_FWD = 5,
        GODE_OP_ODE_BWD = 6, GODE_OP_BCE = 7, GODE_OP_ADAM = 8, GODE_OP_PACK = 9, GODE_OP_ODERNN_FWD = 10,
-       GODE_OP_ODERNN_BWD = 11, GODE_OP_BN_APPLY = 12 };
+       GODE_OP_ODERNN_BWD = 11, GODE_OP_BN_APPLY = 12, GODE_OP_COL2IM = 13 };
 typedef struct gode_pack_op {
   gode_conv_geom g; int32_t dir, co_canon; const float* w; float* wpack; const int32_t* co_perm;
 } gode_pack_op;

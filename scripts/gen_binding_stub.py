@@ -60,7 +60,8 @@ KIND_STRUCT = {"GODE_OP_IGEMM": "gode_igemm_op", "GODE_OP_WGRAD": "gode_wgrad_op
                "GODE_OP_BN_FINALIZE": "gode_bn_finalize_op", "GODE_OP_BN_BWD": "gode_bn_bwd_op",
                "GODE_OP_ODE_FWD": "gode_ode_fwd_op", "GODE_OP_ODE_BWD": "gode_ode_bwd_op", "GODE_OP_BCE": "gode_bce_op",
                "GODE_OP_ADAM": "gode_adam_op", "GODE_OP_PACK": "gode_pack_op", "GODE_OP_ODERNN_FWD": "gode_odernn_fwd_op",
-               "GODE_OP_ODERNN_BWD": "gode_odernn_bwd_op", "GODE_OP_BN_APPLY": "gode_bn_apply_op"}
+               "GODE_OP_ODERNN_BWD": "gode_odernn_bwd_op", "GODE_OP_BN_APPLY": "gode_bn_apply_op",
+               "GODE_OP_COL2IM": "gode_col2im_op"}
 
 
 def generate():
@@ -90,7 +91,7 @@ def generate():
               "    lib.gode_sizeof.argtypes = [C.c_int]",
               "    for kind, st in KINDS.items():            # the mirror must match the compiled ABI, field for field",
               "        assert lib.gode_sizeof(kind) == C.sizeof(st), (kind, st.__name__)",
-              "    for fn in (\"gode_igemm\", \"gode_wgrad\", \"gode_bn_finalize\", \"gode_bn_bwd\", \"gode_bn_apply\", \"gode_ode_fwd\",",
+              "    for fn in (\"gode_igemm\", \"gode_wgrad\", \"gode_bn_finalize\", \"gode_bn_bwd\", \"gode_bn_apply\", \"gode_col2im\", \"gode_ode_fwd\",",
               "               \"gode_ode_bwd\", \"gode_odernn_fwd\", \"gode_odernn_bwd\", \"gode_bce_logits\", \"gode_adam_l2\"):",
               "        getattr(lib, fn).argtypes = [ptr, ptr]          # (const op struct*, hipStream_t)",
               "        getattr(lib, fn).restype = C.c_int              # 0 ok, <0 GODE_E_*, >0 hipError_t",

@@ -401,3 +401,27 @@ def test_full_size_adjoint_identities(case):
     scale = float((fx.double().norm() * y.double().norm()))
     assert abs(a - b) / scale < 1e-6 and abs(a - c) / scale < 1e-6, (a, b, c, scale)
     assert torch.isfinite(fx).all() and torch.isfinite(dy).all() and torch.isfinite(dw).all()
+
+
+@pytest.mark.parametrize("case", [(64, 3, 32, 32, 4, 2, 1, 6, L.EPI_TANH), (32, 2, 9, 13, 3, 2, 0, 3, L.EPI_RAW),
+                                  (32, 4, 8, 8, 4, 1, 2, 2, L.EPI_RAW)])
+def test_thin_conv_transpose_as_pixel_gemm_plus_col2im(case):
+    """ConvTranspose2d with <= 4 output channels = plain GEMM over the input pixels (DGRAD of the kernel-sized geometry,
+    one 'image' per pixel) + gode_col2im; reference: torch's conv_transpose2d on the CPU."""
+    Cin, Cout, H, W, k, s, p, N, epi = case
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Cin, H, W, generator=gen)
+    w = torch.randn(Cin, Cout, k, k, generator=gen) * 0.2          # ConvTranspose2d layout = conv weight [Co=Cin][Ci=Cout]
+    ref = F.conv_transpose2d(x, w, stride=s, padding=p)
+    if epi == L.EPI_TANH:
+        ref = torch.tanh(ref)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    hg = make_geom(N * H * W, Cout, Cin, (1, k, k), (1, 1, 1), (1, k, k), (1, 1, 1), (0, 0, 0))
+    xcl = dev(x.permute(0, 2, 3, 1).contiguous())                # [N, H, W, Cin] = [pixels][Cin]
+    cols, _ = igemm(hg, L.DGRAD, xcl, dev(w.reshape(Cin, Cout, 1, k, k)), (N * H * W, 1, k, k, Cout))
+    out = torch.full((N, Ho, Wo, Cout), float("nan"), device="cuda")
+    op = L.Col2imOp(cols=cols.data_ptr(), out=out.data_ptr(), N=N, Hi=H, Wi=W, Ho=Ho, Wo=Wo, C=Cout, kh=k, kw=k, sh=s, sw=s,
+                    ph=p, pw=p, epilogue=epi)
+    L.run_one(op, stream())
+    torch.cuda.synchronize()
+    assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref) < TOL
