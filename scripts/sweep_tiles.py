@@ -14,7 +14,12 @@ def g3(N, Ci, Co, xi, k, s, p):
     return make_geom(N, Ci, Co, xi, yo, k, s, p)
 
 
-cases = [("mnist vidD L1", g3(32, 64, 128, (15, 15, 15), (2, 2, 2), (1, 2, 2), (0, 1, 1))),
+cases = [("mnist vidD L1 N=64", g3(64, 64, 128, (15, 15, 15), (2, 2, 2), (1, 2, 2), (0, 1, 1))),     # paired D(real)+D(fake) passes
+         ("mnist vidD L2 N=64", g3(64, 128, 256, (14, 8, 8), (2, 2, 2), (1, 2, 2), (0, 1, 1))),
+         ("mnist vidD L3 N=64", g3(64, 256, 512, (13, 5, 5), (2, 2, 2), (1, 2, 2), (0, 1, 1))),
+         ("imgD L1 N=64", make_geom(64, 64, 128, (1, 14, 14), (1, 7, 7), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("imgD L2 N=64", make_geom(64, 128, 256, (1, 7, 7), (1, 3, 3), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("mnist vidD L1", g3(32, 64, 128, (15, 15, 15), (2, 2, 2), (1, 2, 2), (0, 1, 1))),
          ("mnist vidD L2", g3(32, 128, 256, (14, 8, 8), (2, 2, 2), (1, 2, 2), (0, 1, 1))),
          ("mnist vidD L3", g3(32, 256, 512, (13, 5, 5), (2, 2, 2), (1, 2, 2), (0, 1, 1))),
          ("ucf vidD L1", g3(16, 64, 128, (13, 32, 32), (4, 4, 4), (1, 2, 2), (0, 1, 1))),
