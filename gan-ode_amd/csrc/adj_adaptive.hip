@@ -68,11 +68,14 @@ struct AdjSolver {
       v[k] = t;
     }
   }
+  // The transpose tiles are per wave, and a wave's LDS operations execute in issue order: the only thing to guarantee is
+  // that the compiler keeps the stores before the loads (and the previous call's loads before these stores) -- no
+  // workgroup barrier (there were 24 of them per trial step).
   __device__ __forceinline__ f32x4 outer(const f32x4 P, const f32x4 Q) {
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     *reinterpret_cast<f32x4*>(&L->tile[wv][0][s * LDT + 4 * g]) = P;
     *reinterpret_cast<f32x4*>(&L->tile[wv][1][s * LDT + 4 * g]) = Q;
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     f32x4 d = zero4();
 #pragma unroll
     for (int r = 0; r < 4; ++r) d = MFMA16(L->tile[wv][0][(4 * g + r) * LDT + s], L->tile[wv][1][(4 * g + r) * LDT + s], d);
