@@ -730,7 +730,7 @@ static bool wg_patch(const gode_wgrad_op* op, WpArgs* P) {
   if (segs >= (1ll << 31)) return false;
   if (P) {
     P->RB = RB; P->CB = CB; P->PR = PR; P->PL = PL; P->LW = LW; P->nseg = nseg; P->dseg = make_fastdiv((uint32_t)nseg); P->segs = (int)segs;
-    int wgs = (int)(segs / 8 < 1 ? 1 : segs / 8);            // >= 8 segments per workgroup, two workgroups per CU at most
+    int wgs = (int)(segs / 2 < 1 ? 1 : segs / 2);            // >= 2 segments per workgroup, two workgroups per CU at most
     if (wgs > 512) wgs = 512;
     P->segs_per_wg = (int)((segs + wgs - 1) / wgs);
   }
