@@ -8,4 +8,4 @@ for f in igemm wgrad ode ode_valu odernn adj_adaptive elementwise api; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -DGODE_ADJ_DEBUG -c $f.hip -o ../lib/$f.o &
 done; wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libgode.so ../lib/*.o
-cd $D && sed -i 's#/root/repo#/tmp/gode_dbg#g' scripts/exp/dbg_adj.py && python3 scripts/exp/dbg_adj.py
+cd $D && sed -i 's#/root/repo#/tmp/gode_dbg#g' tests/diag/dbg_adj.py && python3 tests/diag/dbg_adj.py

@@ -8,7 +8,7 @@ configs[4] ODE-RNN: tests/test_gpu_odernn.py.)
 
 Gradient sentinel: per OUTPUT CHANNEL of every weight gradient, relative L2 errors between three
 evaluations on the same fp32 draws: the HIP path, the stock fp32 CPU kernels (oracle) and the oracle in float64 (the
-yardstick).  Measured on the box (scripts/diag_channel_errors.py, gpurun_out/chan_{mnist,ucf}.txt): the two fp32
+yardstick).  Measured on the box (tests/diag/diag_channel_errors.py, gpurun_out/chan_{mnist,ucf}.txt): the two fp32
 evaluations sit 5e-4..5e-3 from the float64 one in EVERY generator tensor -- a (Leaky)ReLU/BatchNorm pre-activation
 within rounding of zero near the top of the backward chain flips in fp32 and shifts everything downstream -- so
 "95 % of channels within 1e-3 of float64" is not even met by the CPU reference for most seeds.  What separates

@@ -154,10 +154,10 @@ def test_full_width_mnist_batch32_against_oracle():
     gradients against the CPU oracle on identical weights and seeds.  Frames, logits and loss: 1e-4 relative against
     the fp32 oracle.  Gradients run through 9 train-mode BatchNorms and (Leaky)ReLU kinks: one pre-activation within
     fp32 rounding of zero flips its derivative (1 vs 0.2) and moves single gradient entries by percents in BOTH fp32
-    evaluations (measured: scripts/diag_disc_layers.py, scripts/diag_grad_precision.py), so gradients are judged in
+    evaluations (measured: tests/diag/diag_disc_layers.py, tests/diag/diag_grad_precision.py), so gradients are judged in
     ROBUST relative error (median |a-b| over the tensor / rms of the reference) against the oracle run in float64 on
     the same fp32 draws: see the comment at the assertion for the bound.  A single flipped kink upstream shifts ONE channel of a BatchNorm bias gradient and of the adjacent
-    weight gradient by ~0.5% while every other channel agrees to ~1e-5 (scripts/diag_grad_precision.py prints the
+    weight gradient by ~0.5% while every other channel agrees to ~1e-5 (tests/diag/diag_grad_precision.py prints the
     per-channel picture), so the plain L2 error only gets a sanity bound."""
     import copy
     seed_all(7)
