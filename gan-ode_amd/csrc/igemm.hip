@@ -1008,7 +1008,9 @@ static void choose_fast(const gode_igemm_op* op, const IgemmGeom& G, int* tile_o
     for (int i = 0; i < G.nphase; ++i) tiles_n += (int64_t)gode_ceil_div(G.ph[i].M, bm) * gode_ceil_div(G.Ncols, bn);
     for (int ki = 0; ki < 10; ++ki) {
       const int k = ksplits[ki];
-      if (k > 1 && (min_slabs / k < 4 || out_bytes * k > 192e6 || min_slabs != max_slabs || !even_phases)) break;
+      // (uneven phases: no split once the unsplit grid already covers half the chip -- see above; tiny grids, e.g. the
+      // image discriminator's 7x7 <- 3x3 input gradient with 25 tiles, still gain from one: 29.5 -> ~20 us)
+      if (k > 1 && (min_slabs / k < 4 || out_bytes * k > 192e6 || min_slabs != max_slabs || (!even_phases && tiles_n >= 128))) break;
       const int64_t blocks = tiles_n * k;
       // live-tap launches: tiles of the end planes are short, so the hardware's in-order dispatch evens the CUs out and
       // the whole-rounds quantisation does not apply to the big tile (measured, UCF video-D layer 2 input gradient at
