@@ -2,6 +2,7 @@
 (torch CPU functional ops / oracle.ode_ref) on the same seeded inputs.  Tolerance: north_star's 1e-4 relative
 (fp32); gradients through long reductions get 2e-4."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -425,3 +426,39 @@ def test_thin_conv_transpose_as_pixel_gemm_plus_col2im(case):
     L.run_one(op, stream())
     torch.cuda.synchronize()
     assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref) < TOL
+
+
+def _random_cases(n, seed):
+    """Seeded random conv geometries that steer through the kernel-selection rules: channel counts on and off the vector
+    / FAST-path multiples, thin first layers (patch / thin weight-gradient kernels), temporal kernels with stride 1
+    (live-tap input gradients), odd extents (uneven stride phases), batches around the split-K thresholds."""
+    rng = np.random.RandomState(seed)
+    cases = []
+    while len(cases) < n:
+        three_d = rng.rand() < 0.5
+        Ci = int(rng.choice([1, 2, 3, 4, 8, 24, 32, 64, 96]))
+        Co = int(rng.choice([1, 3, 4, 8, 32, 64, 128]))
+        k = (int(rng.choice([1, 2, 3, 4])) if three_d else 1, int(rng.choice([1, 2, 3, 4])), int(rng.choice([1, 2, 3, 4])))
+        s = (1, int(rng.choice([1, 2])), int(rng.choice([1, 2, 3])))
+        p = (int(rng.choice([0, 1])) if three_d and k[0] > 1 else 0, int(rng.choice([0, 1, 2])), int(rng.choice([0, 1, 2])))
+        xi = (int(rng.randint(k[0], k[0] + 6)) if three_d else 1, int(rng.randint(max(k[1], 3), 40)), int(rng.randint(max(k[2], 3), 40)))
+        if any(p[a] >= k[a] and k[a] > 1 for a in range(3)) or any(p[a] > 0 and k[a] == 1 for a in range(3)):
+            continue
+        yo = tuple(conv_out(xi[a], k[a], s[a], p[a]) for a in range(3))
+        if min(yo) < 1:
+            continue
+        N = int(rng.choice([1, 2, 3, 5, 8, 16]))
+        macs = N * yo[0] * yo[1] * yo[2] * Co * Ci * k[0] * k[1] * k[2]
+        if macs > float(os.environ.get("GODE_FUZZ_MACS", "3e8")) or N * Ci * xi[0] * xi[1] * xi[2] > 4e6:
+            continue
+        cases.append((Ci, Co, xi, k, s, p, N))
+    return cases
+
+
+# GODE_FUZZ="n,seed" widens the sweep for a one-off fuzz run on the GPU box
+_FUZZ = tuple(int(v) for v in os.environ.get("GODE_FUZZ", "48,20261005").split(","))
+
+
+@pytest.mark.parametrize("case", _random_cases(*_FUZZ))
+def test_igemm_random_geometries(case):
+    test_igemm_fprop_dgrad_wgrad(case)
