@@ -1014,8 +1014,8 @@ static void choose_fast(const gode_igemm_op* op, const IgemmGeom& G, int* tile_o
       const int64_t blocks = tiles_n * k;
       // live-tap launches: tiles of the end planes are short, so the hardware's in-order dispatch evens the CUs out and
       // the whole-rounds quantisation does not apply to the big tile (measured, UCF video-D layer 2 input gradient at
-      // N=32, 640 tiles of 128x128 vs 1280 of 128x64: 600 vs 670 us although 640 is 2.5 rounds; at N=16 the smaller
-      // tile with a K split stays ahead, 370 vs 388 us)
+      // N=32, 640 tiles of 128x128 vs 1280 of 128x64: 10 % apart although 640 is 2.5 rounds; at N=16 the smaller tile
+      // with a K split stays ahead by 5 %)
       const double per_cu = (live_taps && t == TILE_128x128 && k == 1 && blocks >= 512) ? blocks / 256.0 : (double)((blocks + 255) / 256);
       const int slabs = gode_ceil_div(max_slabs, k);
       const double eff = (per_cu >= 2 && resident >= 2) ? eff2 : 0.8 * eff2;
@@ -1131,7 +1131,10 @@ static int launch(IgemmArgs& A, bool vec, int max_mblk, bool double_buf, const S
     int mode = ok2 ? (wbytes * 8 < 3 * in_bytes ? 3 : 0) : 0;
     // depth-major rows with dead-tap skipping: the tiles of the end planes are light, so a contiguous run per XCD would
     // leave the XCDs that own them idle -- interleave the m-blocks over the XCDs instead
-    if (A.dmajor > 0 && mode == 3) mode = 2;
+    // -- and NOT the plain order either: it hands an XCD m-blocks 8 apart, i.e. (at 16 tiles per depth plane) only
+    // planes of one weight: UCF video-D layer 2 at N = 32 runs 600 us in the plain order, 845 us with contiguous runs,
+    // 470 us interleaved (scripts/exp/xcd_sweep.py; no other shape of either config moves by more than 2 %)
+    if (A.dmajor > 0) mode = ok2 ? 2 : (ok1 ? 1 : 0);
     if (force == 0) mode = 0;
     if (force == 1 && ok1) mode = 1;
     if (force == 2 && ok2) mode = 2;
