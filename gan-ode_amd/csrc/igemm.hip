@@ -1199,12 +1199,10 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
   // are dead for whole tiles (skipped in the FAST kernel's K loop)
   A.dmajor = 0;
   A.tapskip = igemm_wants_tapskip(op, G);
-  // Depth-major rows make every tile see one or two planes (a plane of >= 128 rows fills tiles by itself and keeps the
-  // image-major order, whose gather is more local).  Measured on the UCF video-D layers, N=32: 13x32x32 planes 954 ->
-  // 831 us image-major; 7x8x8 497 -> 382 us depth-major; 10x16x16 (15 MB gathered, more than an XCD's L2, and each
-  // image's tiles now spread over the whole launch) only 687 -> 672 us, but image-major with two planes per tile was 737.
-  if (A.tapskip && G.ph[0].Mh * G.ph[0].Mw < tile_bm(tile))
-    A.dmajor = op->g.N;
+  // Depth-major rows: every tile sees one or two planes (a small plane) or a slice of one (a plane of >= 128 rows, which
+  // would fill tiles by itself in image-major order too -- but depth-major with the interleaved XCD order below is 4-6 %
+  // faster there as well: UCF video-D layer 1 input gradient 833 -> 800 us at N = 32, 405 -> 381 at N = 16).
+  if (A.tapskip) A.dmajor = op->g.N;
   A.stats_rows = rows;
   A.work = op->work; A.out_numel = (int32_t)outn; A.ksplit = 1; A.slabs_per_split = 0; A.MB = 0; A.NB = 0; A.xcd_mode = 0;
   if ((op->scale == nullptr) != (op->shift == nullptr)) return GODE_E_ARG;
