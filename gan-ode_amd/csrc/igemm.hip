@@ -18,6 +18,8 @@
 #include "common.h"
 #include "conv_geom.h"
 
+int gode_launch_conv_patch_fprop(const gode_igemm_op* op, const int64_t* gs, hipStream_t st);   // conv_patch.hip
+
 struct IgemmArgs {
   IgemmGeom G;
   const float* src;
@@ -1191,6 +1193,10 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
   int64_t outn = (int64_t)op->g.N * G.Xd * G.Xh * G.Xw * G.Ncols;
   for (int i = 0; i < 5; ++i) if (gs[i] < 0) return GODE_E_ARG;
   if (span >= (1ll << 31) || outn >= (1ll << 31)) return GODE_E_SHAPE;
+  if (op->src && op->wpack && op->out && ((uintptr_t)op->wpack % 16) == 0) {      // first layers with 1-4 input channels: conv_patch.hip
+    const int pr = gode_launch_conv_patch_fprop(op, gs, (hipStream_t)stream);
+    if (pr != 0) return pr < 0 ? pr : 0;
+  }
   A.src = op->src; A.w = op->wpack; A.out = op->out; A.scale = op->scale; A.shift = op->shift; A.stats = op->stats;
   A.gsN = (int)gs[0]; A.gsD = (int)gs[1]; A.gsH = (int)gs[2]; A.gsW = (int)gs[3]; A.gsC = (int)gs[4];
   A.act = op->act; A.epilogue = op->epilogue;

@@ -66,3 +66,27 @@ run_wgrad("ucf di L0 wgrad N=16", make_geom(16, 3, 64, (1, 64, 64), (1, 32, 32),
 run_wgrad("mnist dv L0 wgrad N=32", make_geom(32, 1, 64, (16, 28, 28), (15, 15, 15), (2, 2, 2), (1, 2, 2), (0, 1, 1)), strided=True)
 run_wgrad("mnist di L0 wgrad N=32", make_geom(32, 1, 64, (1, 28, 28), (1, 14, 14), (1, 4, 4), (1, 2, 2), (0, 1, 1)))
 run_wgrad("mnist G head wgrad N=512", make_geom(512, 1, 64, (1, 28, 28), (1, 32, 32), (1, 1, 1), (1, 1, 1), (0, 2, 2)), on_y=True)
+
+def run_fprop_strided(name, g, ndchw):
+    if ndchw:   # [N, D, C, H, W] memory (the real-video tensor)
+        xm = torch.randn(g.N, g.Di, g.Ci, g.Hi, g.Wi, device="cuda")
+        xs = (xm.stride(0), xm.stride(1), xm.stride(3), xm.stride(4), xm.stride(2))
+    else:
+        xm = torch.randn(g.N, g.Di, g.Hi, g.Wi, g.Ci, device="cuda"); xs = None
+    w = torch.randn(g.Co, g.Ci, g.kd, g.kh, g.kw, device="cuda") * 0.05
+    wp = torch.empty(lib.gode_pack_size(C.byref(g), L.FPROP), device="cuda")
+    L.check(lib.gode_pack_weights(C.byref(g), L.FPROP, w.data_ptr(), wp.data_ptr(), None, 0, stream_ptr()))
+    out = torch.empty(g.N, g.Do, g.Ho, g.Wo, g.Co, device="cuda")
+    op = L.IgemmOp(g=g, dir=L.FPROP, act=L.ACT_NONE, epilogue=L.EPI_RAW, tile=0, src=xm.data_ptr(), wpack=wp.data_ptr(), out=out.data_ptr())
+    if xs:
+        for i in range(5): op.gs[i] = xs[i]
+    work = torch.empty(max(lib.gode_igemm_work_size(C.byref(op)), 1), device="cuda"); op.work = work.data_ptr()
+    flop = 2.0 * g.N * g.Do * g.Ho * g.Wo * g.Co * g.Ci * g.kd * g.kh * g.kw
+    ms = timeit(op)
+    print(f"{name:40s} {ms*1e3:9.1f} us {flop/ms/1e9:7.1f} TF", flush=True)
+
+run_fprop_strided("ucf dv L0 fprop N=16 (channels-last)", make_geom(16, 3, 64, (16, 64, 64), (13, 32, 32), (4, 4, 4), (1, 2, 2), (0, 1, 1)), False)
+run_fprop_strided("ucf dv L0 fprop N=16 (NDCHW video)", make_geom(16, 3, 64, (16, 64, 64), (13, 32, 32), (4, 4, 4), (1, 2, 2), (0, 1, 1)), True)
+run_fprop_strided("ucf di L0 fprop N=16", make_geom(16, 3, 64, (1, 64, 64), (1, 32, 32), (1, 4, 4), (1, 2, 2), (0, 1, 1)), False)
+run_fprop_strided("mnist dv L0 fprop N=32 (NDCHW)", make_geom(32, 1, 64, (16, 28, 28), (15, 15, 15), (2, 2, 2), (1, 2, 2), (0, 1, 1)), True)
+run_fprop_strided("mnist di L0 fprop N=32", make_geom(32, 1, 64, (1, 28, 28), (1, 14, 14), (1, 4, 4), (1, 2, 2), (0, 1, 1)), False)
