@@ -68,11 +68,16 @@ __global__ void __launch_bounds__(256) probe_kernel(const __bf16* A, const __bf1
   dma(0, 0);
   for (int s = 0; s < nslab; ++s) {
     __syncthreads();
+#ifndef PROBE_NO_DMA      // ablation: -DPROBE_NO_DMA = fragment reads + MFMA only (results wrong)
     if (s + 1 < nslab) dma(s + 1, (s + 1) & 1);
+#endif
     const int buf = s & 1;
 #pragma unroll
     for (int ks = 0; ks < SK / 16; ++ks) {
       bf8 a[2][3], b[2][3];
+#ifdef PROBE_NO_READ     // ablation: -DPROBE_NO_READ = DMA + MFMA only, fragments read once (results wrong)
+      if (s == 0)
+#endif
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
