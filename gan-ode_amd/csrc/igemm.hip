@@ -900,14 +900,14 @@ __global__ void __launch_bounds__(256) conv_smallk_kernel(const PwArgs d) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-enum { TILE_128x128 = 1, TILE_128x64 = 2, TILE_128x32 = 3, TILE_64x64 = 4, TILE_128x128_W8 = 5 };
+enum { TILE_128x128 = 1, TILE_128x64 = 2, TILE_128x32 = 3, TILE_64x64 = 4, TILE_128x128_W8 = 5, TILE_256x128 = 6 };
 
-static int tile_bm(int tile) { return tile == TILE_64x64 ? 64 : 128; }
-static int tile_bn(int tile) { return (tile == TILE_128x128 || tile == TILE_128x128_W8) ? 128 : tile == TILE_128x32 ? 32 : 64; }
+static int tile_bm(int tile) { return tile == TILE_64x64 ? 64 : (tile == TILE_256x128 ? 256 : 128); }
+static int tile_bn(int tile) { return (tile == TILE_128x128 || tile == TILE_128x128_W8 || tile == TILE_256x128) ? 128 : tile == TILE_128x32 ? 32 : 64; }
 
 static int pick_tile(const IgemmGeom& G, int requested) {
   requested %= 10;   // +10: double-LDS-buffer variant of the same tile (tuning knob; default is single-buffer)
-  if (requested >= TILE_128x128 && requested <= TILE_128x128_W8) return requested;
+  if (requested >= TILE_128x128 && requested <= TILE_256x128) return requested;
   if (G.Ncols <= 32) return TILE_128x32;
   if (G.Ncols <= 64) return TILE_128x64;
   int64_t blocks = 0;
@@ -994,25 +994,33 @@ static void choose_fast(const gode_igemm_op* op, const IgemmGeom& G, int* tile_o
     if (ns < min_slabs) min_slabs = ns;
     even_phases = even_phases && G.ph[i].M == G.ph[0].M;
   }
-  static const int tiles[4] = {TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32};
+  // 256x128 (8 waves, one workgroup per CU, 25 % less operand traffic per MFMA) last: 2-3 % ahead of 128x128 on the full
+  // decoder grids and 5 % on the MNIST video-D layer-2 input gradient (scripts/sweep_tiles.py), behind it on grids that
+  // do not fill whole rounds of 256 such tiles
+  static const int tiles[5] = {TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128};
   static const int ksplits[10] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
   const bool live_taps = igemm_wants_tapskip(op, G);
   double best = 1e300;
   int best_tile = G.Ncols <= 32 ? TILE_128x32 : TILE_128x64, best_k = 1;
-  for (int ti = 0; ti < 4; ++ti) {
+  for (int ti = 0; ti < 5; ++ti) {
     const int t = tiles[ti], bm = tile_bm(t), bn = tile_bn(t);
     if (bn >= 2 * G.Ncols && bn > 32) continue;              // more than half of every tile would be padding
     if (t == TILE_128x32 && G.Ncols > 32) continue;
-    const double cps = t == TILE_128x128 ? 4096.0 : (t == TILE_128x64 ? 2048.0 : 1024.0);
-    const int resident = t == TILE_128x128 ? 2 : (t == TILE_128x64 ? 3 : 4);
-    const double eff2 = (t == TILE_64x64 || t == TILE_128x32) ? 0.62 : 0.76;
+    if (t == TILE_256x128 && (live_taps || op->groups == 2)) continue;     // (measured on plain launches only)
+    const double cps = t == TILE_256x128 ? 8192.0 : (t == TILE_128x128 ? 4096.0 : (t == TILE_128x64 ? 2048.0 : 1024.0));
+    const int resident = t == TILE_256x128 ? 1 : (t == TILE_128x128 ? 2 : (t == TILE_128x64 ? 3 : 4));
+    const double eff2 = (t == TILE_64x64 || t == TILE_128x32) ? 0.62 : (t == TILE_256x128 ? 0.785 : 0.76);
     int64_t tiles_n = 0;
     for (int i = 0; i < G.nphase; ++i) tiles_n += (int64_t)gode_ceil_div(G.ph[i].M, bm) * gode_ceil_div(G.Ncols, bn);
+    if (t == TILE_256x128 && tiles_n < 192) continue;        // one workgroup per CU: needs a grid that covers the chip
     for (int ki = 0; ki < 10; ++ki) {
       const int k = ksplits[ki];
       // (uneven phases: no split once the unsplit grid already covers half the chip -- see above; tiny grids, e.g. the
       // image discriminator's 7x7 <- 3x3 input gradient with 25 tiles, still gain from one: 29.5 -> ~20 us)
       if (k > 1 && (min_slabs / k < 4 || out_bytes * k > 192e6 || min_slabs != max_slabs || (!even_phases && tiles_n >= 128))) break;
+      // the 256x128 tile only unsplit (measured with K splits: never ahead); live-tap launches split only grids that do
+      // not fill the chip (UCF video-D layer 2 input gradient at N = 16: 269 us unsplit, 318 us split 2 ways)
+      if (k > 1 && (t == TILE_256x128 || (live_taps && tiles_n >= 256))) break;
       const int64_t blocks = tiles_n * k;
       // live-tap launches: tiles of the end planes are short, so the hardware's in-order dispatch evens the CUs out and
       // the whole-rounds quantisation does not apply to the big tile (measured, UCF video-D layer 2 input gradient at
@@ -1020,7 +1028,7 @@ static void choose_fast(const gode_igemm_op* op, const IgemmGeom& G, int* tile_o
       // with a K split stays ahead by 5 %)
       const double per_cu = (live_taps && t == TILE_128x128 && k == 1 && blocks >= 512) ? blocks / 256.0 : (double)((blocks + 255) / 256);
       const int slabs = gode_ceil_div(max_slabs, k);
-      const double eff = (per_cu >= 2 && resident >= 2) ? eff2 : 0.8 * eff2;
+      const double eff = ((per_cu >= 2 && resident >= 2) || t == TILE_256x128) ? eff2 : 0.8 * eff2;    // (8 waves cover their own barriers)
       double cyc = per_cu * (4000.0 + slabs * cps / eff);
       if (k > 1) cyc += 2.4e9 * (2.5e-6 + (k + 1) * out_bytes / 3e12);
       if (cyc < best * 0.97) { best = cyc; best_tile = t; best_k = k; }   // 3 % hysteresis toward the earlier (larger) choice
@@ -1273,6 +1281,7 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
     case TILE_128x32: return launch<4, 1, 1, 1>(A, vec, max_mblk, sb, sp, st);
     case TILE_64x64: return launch<2, 2, 1, 1>(A, vec, max_mblk, sb, sp, st);
     case TILE_128x128_W8: return launch<4, 2, 1, 2>(A, vec, max_mblk, sb, sp, st);
+    case TILE_256x128: return launch<4, 2, 2, 2>(A, vec, max_mblk, sb, sp, st);
   }
   return GODE_E_ARG;
 }

@@ -14,7 +14,10 @@ def g3(N, Ci, Co, xi, k, s, p):
     return make_geom(N, Ci, Co, xi, yo, k, s, p)
 
 
-cases = [("ucf dec L1 N=256", make_geom(256, 256, 512, (1, 8, 8), (1, 4, 4), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
+cases = [("dec L1 N=512", make_geom(512, 256, 512, (1, 8, 8), (1, 4, 4), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("dec L2 N=512", make_geom(512, 128, 256, (1, 16, 16), (1, 8, 8), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("dec L3 N=512", make_geom(512, 64, 128, (1, 32, 32), (1, 16, 16), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("ucf dec L1 N=256", make_geom(256, 256, 512, (1, 8, 8), (1, 4, 4), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
          ("ucf dec L2 N=256", make_geom(256, 128, 256, (1, 16, 16), (1, 8, 8), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
          ("mnist vidD L1 N=64", g3(64, 64, 128, (15, 15, 15), (2, 2, 2), (1, 2, 2), (0, 1, 1))),     # paired D(real)+D(fake) passes
          ("mnist vidD L2 N=64", g3(64, 128, 256, (14, 8, 8), (2, 2, 2), (1, 2, 2), (0, 1, 1))),
@@ -43,7 +46,7 @@ for name, g in cases:
         out = torch.empty(out_dims, device="cuda")
         fl = 2.0 * g.N * g.Do * g.Ho * g.Wo * g.Co * g.Ci * g.kd * g.kh * g.kw
         res = []
-        for force in ["model"] + [f"{t},{k}" for t in (1, 2, 4, 5) for k in (1, 2, 3, 4, 8, 16)]:
+        for force in ["model"] + [f"{t},{k}" for t in (1, 2, 4, 5, 6) for k in (1, 2, 3, 4, 8, 16)]:
             if force == "model":
                 os.environ.pop("GODE_IGEMM_FORCE", None)
             else:
