@@ -180,8 +180,8 @@ __device__ __attribute__((aligned(16))) const float gode_wg_zero16[4] = {0.f, 0.
 // GL: transform-free operands go global -> LDS by `global_load_lds_dwordx4` (the [position][channel] image is already
 // lane-linear: thread t of a loader pass owns 16-byte chunk t), two LDS buffers, one barrier per 32-position slab.
 template <int WM, int WN, int TM, int TN, bool GL>
-__global__ void __launch_bounds__(256) wgrad_fast_kernel(const WgradArgs a) {
-  constexpr int NT = 256, BI = WM * TM * 32, BJ = WN * TN * 32;
+__global__ void __launch_bounds__(WM* WN * 64) wgrad_fast_kernel(const WgradArgs a) {
+  constexpr int NT = WM * WN * 64, BI = WM * TM * 32, BJ = WN * TN * 32;
   constexpr int YC = BI / 4, XC = BJ / 4, YR = NT / YC, XR = NT / XC, YP = 32 / YR, XP = 32 / XR;
   static_assert(YP >= 1 && XP >= 1, "tile too narrow for the loader");
   static_assert(!GL || (YC % 64 == 0 || 64 % YC == 0), "loader pass must be lane-linear");
@@ -675,8 +675,15 @@ __global__ void __launch_bounds__(256) wgrad_reduce_small_kernel(const float* wo
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-static int wg_tile(const gode_conv_geom& g) { return g.Co <= 32 ? 0 : (g.Co <= 64 ? 1 : 2); }
-static int wg_bi(int t) { return t == 0 ? 32 : (t == 1 ? 64 : 128); }
+// 3: 256 output channels x 128 weight columns, 8 waves (FAST kernel only): 25 % fewer operand bytes per MFMA than 128 x 128.
+// Measured: decoder layers 332 -> 310 and 313 -> 304 us, MNIST video-D layers 2 / 3 at N = 64 119 -> 112 and 144 -> 135 us;
+// a 0.6-GFLOP problem (image-D layer 2) loses 15 %, hence the size floor.
+static int wg_tile(const gode_conv_geom& g) {
+  const int64_t macs = (int64_t)g.N * g.Do * g.Ho * g.Wo * g.Co * g.Ci * g.kd * g.kh * g.kw;
+  if (g.Co % 256 == 0 && g.Ci % 4 == 0 && macs >= (1ll << 31)) return 3;
+  return g.Co <= 32 ? 0 : (g.Co <= 64 ? 1 : 2);
+}
+static int wg_bi(int t) { return t == 0 ? 32 : (t == 1 ? 64 : (t == 3 ? 256 : 128)); }
 
 // Position splits of the weight-gradient GEMM.  All workgroups carry equal work, so the launch time is the busiest
 // CU's share: the grid (tiles x splits) should be a multiple of the 256 CUs and give each CU >= 2 resident workgroups
@@ -756,7 +763,7 @@ extern "C" int64_t gode_wgrad_work_size(const gode_wgrad_op* op) {
 template <int WM, int WN, int TM, int TN>
 static int wg_launch(const WgradArgs& A, bool vx, bool vy, int splits, hipStream_t st) {
   constexpr int BI = WM * TM * 32, BJ = WN * TN * 32;
-  dim3 grid(gode_ceil_div(A.Kt, BJ), gode_ceil_div(A.g.Co, BI), splits), block(256);
+  dim3 grid(gode_ceil_div(A.Kt, BJ), gode_ceil_div(A.g.Co, BI), splits), block(WM * WN * 64);
   static const char* genv = getenv("GODE_WGRAD_GLDS");
   const bool glds = (genv ? atoi(genv) != 0 : true) && A.scale == nullptr && A.act == GODE_ACT_NONE;
   if (vx && vy && getenv("GODE_WGRAD_GENERIC") == nullptr) {
@@ -824,6 +831,15 @@ extern "C" int gode_wgrad(const gode_wgrad_op* op, void* stream) {
     rc = 0;
   } else if (t == 0) rc = wg_launch<1, 4, 1, 1>(A, vx, vy, splits, st);
   else if (t == 1) rc = wg_launch<2, 2, 1, 2>(A, vx, vy, splits, st);
+  else if (t == 3 && vx && vy && getenv("GODE_WGRAD_GENERIC") == nullptr) {
+    constexpr int BI = 256, BJ = 128;
+    dim3 grid(gode_ceil_div(A.Kt, BJ), gode_ceil_div(g.Co, BI), splits), block(512);
+    const bool glds = A.scale == nullptr && A.act == GODE_ACT_NONE;
+    if (glds) hipLaunchKernelGGL((wgrad_fast_kernel<4, 2, 2, 2, true>), grid, block, 0, st, A);
+    else hipLaunchKernelGGL((wgrad_fast_kernel<4, 2, 2, 2, false>), grid, block, 0, st, A);
+    GODE_LAUNCH_CHECK();
+    rc = 0;
+  }
   else rc = wg_launch<2, 2, 2, 2>(A, vx, vy, splits, st);
   if (rc) return rc;
   const int64_t total = (int64_t)g.Co * A.Kt;
