@@ -681,9 +681,13 @@ __global__ void __launch_bounds__(256) wgrad_reduce_small_kernel(const float* wo
 static int wg_tile(const gode_conv_geom& g) {
   const int64_t macs = (int64_t)g.N * g.Do * g.Ho * g.Wo * g.Co * g.Ci * g.kd * g.kh * g.kw;
   if (g.Co % 256 == 0 && g.Ci % 4 == 0 && macs >= (1ll << 31)) return 3;
+  // 128 x 256, 8 waves: the decoder's last stride-2 layer (326 -> 321 us); with only two column tiles (MNIST video-D
+  // layer 1, Kt = 512) it needs 128 position splits and loses 12 %
+  if (g.Co == 128 && g.Ci % 4 == 0 && (g.kd * g.kh * g.kw * g.Ci) % 256 == 0 && g.kd * g.kh * g.kw * g.Ci >= 1024 && macs >= (1ll << 31)) return 4;
   return g.Co <= 32 ? 0 : (g.Co <= 64 ? 1 : 2);
 }
 static int wg_bi(int t) { return t == 0 ? 32 : (t == 1 ? 64 : (t == 3 ? 256 : 128)); }
+static int wg_bj(int t) { return t == 4 ? 256 : 128; }
 
 // Position splits of the weight-gradient GEMM.  All workgroups carry equal work, so the launch time is the busiest
 // CU's share: the grid (tiles x splits) should be a multiple of the 256 CUs and give each CU >= 2 resident workgroups
@@ -692,7 +696,9 @@ static int wg_bi(int t) { return t == 0 ? 32 : (t == 1 ? 64 : (t == 3 ? 256 : 12
 extern "C" int gode_wgrad_auto_splits(const gode_conv_geom* g) {
   const int taps = g->kd * g->kh * g->kw, Kt = taps * g->Ci;
   const int64_t M = (int64_t)g->N * g->Do * g->Ho * g->Wo;
-  const int64_t tiles = (int64_t)gode_ceil_div(g->Co, wg_bi(wg_tile(*g))) * gode_ceil_div(Kt, 128);
+  const int wt = wg_tile(*g);
+  const bool w8 = wt >= 3;          // 8-wave tiles: one workgroup per CU (96 KB of LDS), its waves cover each other's barriers
+  const int64_t tiles = (int64_t)gode_ceil_div(g->Co, wg_bi(wt)) * gode_ceil_div(Kt, wg_bj(wt));
   int64_t cap = (M + 63) / 64;
   if (cap > 256) cap = 256;
   if (cap < 1) cap = 1;
@@ -701,7 +707,7 @@ extern "C" int gode_wgrad_auto_splits(const gode_conv_geom* g) {
     const double blocks = (double)(tiles * s);
     const double rounds = (double)((tiles * s + 255) / 256);
     const double balance = blocks / (rounds * 256.0);                 // busiest CU's share vs the mean
-    const double overlap = blocks >= 512.0 ? 1.0 : 0.92;              // a lone workgroup per CU cannot hide its barriers
+    const double overlap = (blocks >= 512.0 || w8) ? 1.0 : 0.92;      // a lone 4-wave workgroup per CU cannot hide its barriers
     const double cost = (1.0 + 114.0 * (double)s / (double)M) / (balance * overlap);
     if (cost < best_cost - 1e-12) { best_cost = cost; best = (int)s; }
   }
@@ -831,12 +837,16 @@ extern "C" int gode_wgrad(const gode_wgrad_op* op, void* stream) {
     rc = 0;
   } else if (t == 0) rc = wg_launch<1, 4, 1, 1>(A, vx, vy, splits, st);
   else if (t == 1) rc = wg_launch<2, 2, 1, 2>(A, vx, vy, splits, st);
-  else if (t == 3 && vx && vy && getenv("GODE_WGRAD_GENERIC") == nullptr) {
-    constexpr int BI = 256, BJ = 128;
-    dim3 grid(gode_ceil_div(A.Kt, BJ), gode_ceil_div(g.Co, BI), splits), block(512);
+  else if (t >= 3 && vx && vy && getenv("GODE_WGRAD_GENERIC") == nullptr) {
+    dim3 grid(gode_ceil_div(A.Kt, wg_bj(t)), gode_ceil_div(g.Co, wg_bi(t)), splits), block(512);
     const bool glds = A.scale == nullptr && A.act == GODE_ACT_NONE;
-    if (glds) hipLaunchKernelGGL((wgrad_fast_kernel<4, 2, 2, 2, true>), grid, block, 0, st, A);
-    else hipLaunchKernelGGL((wgrad_fast_kernel<4, 2, 2, 2, false>), grid, block, 0, st, A);
+    if (t == 3) {
+      if (glds) hipLaunchKernelGGL((wgrad_fast_kernel<4, 2, 2, 2, true>), grid, block, 0, st, A);
+      else hipLaunchKernelGGL((wgrad_fast_kernel<4, 2, 2, 2, false>), grid, block, 0, st, A);
+    } else {
+      if (glds) hipLaunchKernelGGL((wgrad_fast_kernel<2, 4, 2, 2, true>), grid, block, 0, st, A);
+      else hipLaunchKernelGGL((wgrad_fast_kernel<2, 4, 2, 2, false>), grid, block, 0, st, A);
+    }
     GODE_LAUNCH_CHECK();
     rc = 0;
   }
