@@ -38,13 +38,14 @@ struct __attribute__((aligned(16))) AdjLds {
   float tile[4][2][16 * LDT];   // per-wave transpose tiles of the outer products
   float img[4][2][TH_N];        // per-wave images of theta-shaped quantities (slot 0: V / E, slot 1: S)
   float gtot[TH_N];             // workgroup total of the accepted theta state of the current adjoint call
-  float red[4][8];
+  float red[2][4][8];
 };
 
 struct AdjSolver {
   f32x4 w1, w2, w1t, w2t, b1, b2;
   float rtol, atol, inv_ya;
   int s, g, wv, nw;
+  int red_par = 0;
   bool valid;
   AdjLds* L;
 
@@ -55,18 +56,18 @@ struct AdjSolver {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
     }
-    __syncthreads();
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) L->red[wv][k] = v[k];
+      for (int k = 0; k < 6; ++k) L->red[red_par][wv][k] = v[k];
     }
-    __syncthreads();
+    __syncthreads();       // one barrier per call: the slot sets alternate (see block_sum in odernn.hip)
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       float t = 0.f;
-      for (int w = 0; w < nw; ++w) t += L->red[w][k];
+      for (int w = 0; w < nw; ++w) t += L->red[red_par][w][k];
       v[k] = t;
     }
+    red_par ^= 1;
   }
   // The transpose tiles are per wave, and a wave's LDS operations execute in issue order: the only thing to guarantee is
   // that the compiler keeps the stores before the loads (and the previous call's loads before these stores) -- no

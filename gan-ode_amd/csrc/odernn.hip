@@ -26,14 +26,17 @@
 #define RO_BIH 2080
 #define RO_BHH 2128
 
-__device__ __forceinline__ float block_sum(float v, float* red, int nw) {
+// Workgroup sum, every thread gets the total (fixed order).  red[2][...] alternates per call, so ONE barrier per call
+// suffices: a wave can write slot set p again only after passing the barrier of the call in between, which every wave
+// reaches after its reads of p.
+__device__ __forceinline__ float block_sum(float v, float (*red)[RNN_BLOCK_SAMPLES / 16], int nw, int& par) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0) red[par][threadIdx.x >> 6] = v;
   __syncthreads();
   float s = 0.f;
-  for (int w = 0; w < nw; ++w) s += red[w];
+  for (int w = 0; w < nw; ++w) s += red[par][w];
+  par ^= 1;
   return s;
 }
 __device__ __forceinline__ float sq4(const f32x4 v) { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
@@ -43,7 +46,8 @@ __device__ __forceinline__ f32x4 max4(const f32x4 a, const f32x4 b) {
 }
 
 __global__ void __launch_bounds__(RNN_BLOCK_SAMPLES * 4) odernn_fwd_kernel(const gode_odernn_fwd_op a) {
-  __shared__ float red[RNN_BLOCK_SAMPLES / 16];
+  __shared__ float red[2][RNN_BLOCK_SAMPLES / 16];
+  int red_par = 0;
   const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int s = l & 15, g = l >> 4;
   const int n = blockIdx.x * RNN_BLOCK_SAMPLES + wv * 16 + s;
@@ -61,7 +65,7 @@ __global__ void __launch_bounds__(RNN_BLOCK_SAMPLES * 4) odernn_fwd_kernel(const
     wih[q] = ld4(a.p.Wih + (16 * q + s) * 16 + 4 * g); whh[q] = ld4(a.p.Whh + (16 * q + s) * 16 + 4 * g);
     bih[q] = ld4(a.p.bih + 16 * q + 4 * g); bhh[q] = ld4(a.p.bhh + 16 * q + 4 * g);
   }
-  auto rms = [&](const f32x4 v) { return sqrtf(block_sum(valid ? sq4(v) : 0.f, red, nw) * inv_count); };
+  auto rms = [&](const f32x4 v) { return sqrtf(block_sum(valid ? sq4(v) : 0.f, red, nw, red_par) * inv_count); };
 
   const int tsel = (a.sel_t && valid) ? a.sel_t[n] : -1;
   f32x4 h = valid ? ld4(a.noise + (int64_t)n * 16 + 4 * g) : zero4();
@@ -160,7 +164,8 @@ __global__ void __launch_bounds__(256) latent_content_kernel(const float* conten
 // RKAdaptiveStepsizeODESolver flow (advance while target > t1, then evaluate).  Step control, error norm and clock as in
 // odernn_fwd_kernel.  The interpolation abscissa is formed from the fp32-rounded times as torchdiffeq does.
 __global__ void __launch_bounds__(RNN_BLOCK_SAMPLES * 4) ode_dopri5_fwd_kernel(const gode_ode_fwd_op a) {
-  __shared__ float red[RNN_BLOCK_SAMPLES / 16];
+  __shared__ float red[2][RNN_BLOCK_SAMPLES / 16];
+  int red_par = 0;
   const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int s = l & 15, g = l >> 4;
   const int n = blockIdx.x * RNN_BLOCK_SAMPLES + wv * 16 + s;
@@ -186,7 +191,7 @@ __global__ void __launch_bounds__(RNN_BLOCK_SAMPLES * 4) ode_dopri5_fwd_kernel(c
   const f32x4 w1 = ld4(a.p.W1 + s * 16 + 4 * g), w2 = ld4(a.p.W2 + s * 16 + 4 * g);
   const f32x4 b1 = ld4(a.p.b1 + 4 * g), b2 = ld4(a.p.b2 + 4 * g);
   auto f = [&](const f32x4 yy) { return matvec(w2, tanh4(matvec(w1, yy, b1)), b2); };
-  auto rms = [&](const f32x4 v) { return sqrtf(block_sum(valid ? sq4(v) : 0.f, red, nw) * inv_count); };
+  auto rms = [&](const f32x4 v) { return sqrtf(block_sum(valid ? sq4(v) : 0.f, red, nw, red_par) * inv_count); };
   const int tsel = (a.sel_t && valid) ? a.sel_t[n] : -1;
   auto emit = [&](int t, const f32x4 v) {
     if (!valid) return;
