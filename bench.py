@@ -321,7 +321,7 @@ def _rank_main(a):
     # the same iteration replayed from a HIP graph (single process only): the host then only draws the noise, uploads
     # it and launches the graph (GanTrainer(graph=True)); bit-identical results (tests/test_gpu_api.py)
     it_graph_ms = None
-    if not distributed and a.config != "odernn" and not a.no_graph:
+    if not distributed and not a.no_graph:
         trg = G.GanTrainer(gen, dv, di, graph=True)
         trg.gen_opt, trg.vid_opt, trg.img_opt = tr.gen_opt, tr.vid_opt, tr.img_opt     # continue the same optimiser state
         it_graph_ms = _timed(lambda: trg.step(imgs, vids), k, max(3, wtr), distributed) / k * 1e3

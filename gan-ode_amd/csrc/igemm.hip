@@ -1115,7 +1115,8 @@ template <int WM, int WN, int TM, int TN>
 static int launch(IgemmArgs& A, bool vec, int max_mblk, bool double_buf, const SplitPlan& sp, hipStream_t st) {
   constexpr int BN = WN * TN * 32;
   dim3 grid(max_mblk, gode_ceil_div(A.G.Ncols, BN), A.G.nphase), block(WM * WN * 64);
-  bool fast = vec && fast_geometry(A.G) && (sp.ksplit > 1 || getenv("GODE_IGEMM_GENERIC") == nullptr);
+  static const bool generic_forced = getenv("GODE_IGEMM_GENERIC") != nullptr;     // read once per process
+  bool fast = vec && fast_geometry(A.G) && (sp.ksplit > 1 || !generic_forced);
   if (sp.ksplit > 1 && (!fast || A.work == nullptr)) return GODE_E_ARG;   // the plan needs the FAST path + workspace
   A.ksplit = sp.ksplit; A.slabs_per_split = sp.slabs_per_split;
   if (fast) {

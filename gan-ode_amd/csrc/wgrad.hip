@@ -737,7 +737,9 @@ static bool wg_patch(const gode_wgrad_op* op, WpArgs* P) {
   if (PR > 255 || LW > 32767 || PR * LW * g.Ci > 256 * WP_MAXE) return false;
   int PL = LW * g.Ci;
   while (PL % 32 != (g.kw * g.Ci) % 32) ++PL;
-  if (2 * (PR * PL + 32 * g.Co + 4) * 4 > 64 * 1024 || 256 % (g.Co / 4) != 0 || PR > 30 || g.kd > 30 || g.kh > 30) return false;
+  if (2 * (PR * PL + 32 * g.Co + 4) * 4 > 64 * 1024 || 256 % (g.Co / 4) != 0 || PR > 30) return false;
+  // the kernel packs tap-validity masks into one word: depth taps in bits 0..4, row taps from bit 5 (e_key's 5-bit fields)
+  if (g.kd > 5 || g.kh > 27) return false;
   const int nseg = (g.Wo + 31) / 32;
   const int64_t segs = (int64_t)g.N * g.Do * g.Ho * nseg;
   if (segs >= (1ll << 31)) return false;
@@ -766,13 +768,17 @@ extern "C" int64_t gode_wgrad_work_size(const gode_wgrad_op* op) {
   return (int64_t)wg_splits(op) * op->g.Co * taps * op->g.Ci;
 }
 
+static bool wg_generic_forced() {
+  static const bool f = getenv("GODE_WGRAD_GENERIC") != nullptr;     // read once per process
+  return f;
+}
 template <int WM, int WN, int TM, int TN>
 static int wg_launch(const WgradArgs& A, bool vx, bool vy, int splits, hipStream_t st) {
   constexpr int BI = WM * TM * 32, BJ = WN * TN * 32;
   dim3 grid(gode_ceil_div(A.Kt, BJ), gode_ceil_div(A.g.Co, BI), splits), block(WM * WN * 64);
   static const char* genv = getenv("GODE_WGRAD_GLDS");
   const bool glds = (genv ? atoi(genv) != 0 : true) && A.scale == nullptr && A.act == GODE_ACT_NONE;
-  if (vx && vy && getenv("GODE_WGRAD_GENERIC") == nullptr) {
+  if (vx && vy && !wg_generic_forced()) {
     if (glds) hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, true>), grid, block, 0, st, A);
     else hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, false>), grid, block, 0, st, A);
   }
@@ -837,7 +843,7 @@ extern "C" int gode_wgrad(const gode_wgrad_op* op, void* stream) {
     rc = 0;
   } else if (t == 0) rc = wg_launch<1, 4, 1, 1>(A, vx, vy, splits, st);
   else if (t == 1) rc = wg_launch<2, 2, 1, 2>(A, vx, vy, splits, st);
-  else if (t >= 3 && vx && vy && getenv("GODE_WGRAD_GENERIC") == nullptr) {
+  else if (t >= 3 && vx && vy && !wg_generic_forced()) {
     dim3 grid(gode_ceil_div(A.Kt, wg_bj(t)), gode_ceil_div(g.Co, wg_bi(t)), splits), block(512);
     const bool glds = A.scale == nullptr && A.act == GODE_ACT_NONE;
     if (t == 3) {

@@ -271,18 +271,22 @@ class _GenPlan:
         if self.select:
             buf[nx + n * 50:nx + n * 51].view(torch.int32).copy_(sel_host)
 
+    def _decoder_into(self, arena):
+        """Per decoder layer (weight, gamma, beta gradient targets, accumulate?) inside the trainer's arena: the first
+        writer of an optimiser step stores, later ones add."""
+        into = []
+        for lp in self.gen._decoder_params():
+            wt, acc = arena.target(lp.weight)
+            gt = bt = None
+            if lp.gamma is not None:
+                gt, _ = arena.target(lp.gamma)
+                bt, _ = arena.target(lp.beta)
+            into.append((wt, gt, bt, acc))
+        return into
+
     def backward(self, gout, arena=None):
         if arena is not None:
-            # gradients go straight into the trainer's arena (first writer of a step stores, later ones add)
-            into = []
-            for lp in self.gen._decoder_params():
-                wt, acc = arena.target(lp.weight)
-                gt = bt = None
-                if lp.gamma is not None:
-                    gt, _ = arena.target(lp.gamma)
-                    bt, _ = arena.target(lp.beta)
-                into.append((wt, gt, bt, acc))
-            _, _, gz = self.stack.backward(gout, need_input_grad=True, into=into)
+            _, _, gz = self.stack.backward(gout, need_input_grad=True, into=self._decoder_into(arena))
             ode = [q for q in self._ode_params() if q is not None]
             tgt = [arena.target(q) for q in ode]
             base, acc = tgt[0]
@@ -695,16 +699,66 @@ class _RnnGenPlan(_GenPlan):
         self.bwd_op.rtol, self.bwd_op.atol = self.gen.ode_rtol, self.gen.ode_atol
         self.bwd_op.substeps = self.gen.adjoint_substeps
 
-    def backward(self, gout):
+    def backward(self, gout, arena=None):
+        if arena is not None:
+            # decoder gradients and the 2176 ODEFunc + GRU gradients go straight into the trainer's arena: the eight
+            # tensors are its tail, contiguous in the kernel's output order (VideoGeneratorMNISTODERNN._arena_tail)
+            _, _, gz = self.stack.backward(gout, need_input_grad=True, into=self._decoder_into(arena))
+            tgt = [arena.target(q) for q in self._rnn_params()]
+            base, acc = tgt[0]
+            self.bwd_op.gz = gz.data_ptr()
+            self.bwd_op.grads = base.data_ptr()
+            self.bwd_op.accumulate = 1 if acc else 0
+            L.run_one(self.bwd_op, stream_ptr())
+            self.busy = False
+            return None, None
         flat, views, gz = self.stack.backward(gout, need_input_grad=True)
         grads = torch.empty(L.ODERNN_NPARAM, dtype=torch.float32, device=self.device)
         self.bwd_op.gz = gz.data_ptr()
         self.bwd_op.grads = grads.data_ptr()
+        self.bwd_op.accumulate = 0
         L.run_one(self.bwd_op, stream_ptr())
         self.busy = False
-        offs = [(0, 256, (16, 16)), (256, 16, (16,)), (272, 256, (16, 16)), (528, 16, (16,)),
-                (544, 768, (48, 16)), (1312, 768, (48, 16)), (2080, 48, (48,)), (2128, 48, (48,))]
-        return views, [grads[o:o + n].view(shp) for o, n, shp in offs]
+        return views, [grads[o:o + n].view(shp) for o, n, shp in _RNN_GRAD_OFFS]
+
+
+_RNN_GRAD_OFFS = [(0, 256, (16, 16)), (256, 16, (16,)), (272, 256, (16, 16)), (528, 16, (16,)),
+                  (544, 768, (48, 16)), (1312, 768, (48, 16)), (2080, 48, (48,)), (2128, 48, (48,))]
+
+
+class _RnnLatentFn(torch.autograd.Function):
+    """VideoGeneratorMNISTODERNN.sample_z_m as its own autograd node: gode_odernn_fwd alone (latent rows [N*T, 16],
+    row n*T + t = h_{t+1}), backward = gode_odernn_bwd (GRU backward + adaptive adjoint per frame)."""
+
+    @staticmethod
+    def forward(ctx, gen, noise_host, n, T, *params):
+        dev = gen.main[0].weight.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        noise = noise_host.to(dev)                                    # [T+1, n, 16]: h_0, e_1 .. e_T
+        hp = torch.empty(n, T, 16, **f32)
+        z = torch.empty(n * T, 68, **f32)                             # the kernel's latent-row layout; columns 0..15 used
+        nsteps = torch.zeros((n + 63) // 64 * T, dtype=torch.int32, device=dev)
+        prm = L.OdeRnnParams(*[dptr(p) for p in params])
+        fop = L.OdeRnnFwdOp(p=prm, noise=dptr(noise), content=None, sel_t=None, z=dptr(z), hs=None, hp=dptr(hp),
+                            nsteps=dptr(nsteps), N=n, T=T, rtol=gen.ode_rtol, atol=gen.ode_atol, zcols=68)
+        L.run_one(fop, stream_ptr())
+        ctx.keep = (gen, noise, hp, n, T, [p.detach() for p in params])
+        ctx.nsteps = nsteps
+        return z[:, :16].contiguous()
+
+    @staticmethod
+    def backward(ctx, gout):
+        gen, noise, hp, n, T, params = ctx.keep
+        dev = noise.device
+        g = gout.contiguous()
+        grads = torch.empty(L.ODERNN_NPARAM, dtype=torch.float32, device=dev)
+        work = torch.empty(L.lib().gode_odernn_bwd_work_size(n), dtype=torch.float32, device=dev)
+        prm = L.OdeRnnParams(*[dptr(p) for p in params])
+        bop = L.OdeRnnBwdOp(p=prm, noise=dptr(noise), hp=dptr(hp), sel_t=None, gz=dptr(g), work=dptr(work),
+                            grads=dptr(grads), N=n, T=T, substeps=gen.adjoint_substeps, accumulate=0, zcols=16,
+                            rtol=gen.ode_rtol, atol=gen.ode_atol)
+        L.run_one(bop, stream_ptr())
+        return (None, None, None, None, *[grads[o:o + k].view(shp) for o, k, shp in _RNN_GRAD_OFFS])
 
 
 class VideoGeneratorMNISTODERNN(VideoGeneratorMNIST):
@@ -714,9 +768,6 @@ class VideoGeneratorMNISTODERNN(VideoGeneratorMNIST):
     Noise: the reference calls T.FloatTensor(n, d).normal_() (models/mocogan.py:297-301), i.e. the DEVICE generator on
     a GPU; here it is always drawn from the global torch CPU generator in the same order and copied to the device, so
     that runs are comparable with the CPU oracle at identical seeds ("ROCm .cuda() semantics")."""
-
-    _gode_direct_grads = False     # its plan keeps the stock autograd accumulation
-
 
     _plan_cls = _RnnGenPlan
     ode_rtol, ode_atol = 1e-7, 1e-9
@@ -751,9 +802,23 @@ class VideoGeneratorMNISTODERNN(VideoGeneratorMNIST):
     def _take_trajectories(noise, traj):
         return noise[:, traj].contiguous()        # noise stack [T+1, n, 16]: trajectories are the middle axis
 
+    def _draw_motion(self, num_samples, T):
+        """h_0 and one e_t per frame, each a fresh FloatTensor(n, d).normal_() on the global torch CPU generator
+        (models/mocogan.py:297-301; call order of models/mocogan_ode_rnn.py:42-46) -> [T+1, n, 16]."""
+        buf = torch.empty(T + 1, num_samples, self.dim_z_motion)
+        for i in range(T + 1):
+            buf[i].normal_()
+        return buf
+
     def sample_z_m(self, num_samples, video_len=None):
-        raise NotImplementedError("VideoGeneratorMNISTODERNN.sample_z_m: the ODE-RNN latent is produced inside "
-                                  "sample_videos()/sample_images() (gode_odernn_fwd); it is not exposed on its own")
+        """models/mocogan_ode_rnn.py:39-51 -> [N*T, 16], row n*T + t = h_{t+1}: one gode_odernn_fwd launch, differentiable
+        (gode_odernn_bwd).  sample_videos()/sample_images() fuse the same launch with the content broadcast and the
+        decoder; this method is the reference's public surface (and what the inherited sample_z_video calls)."""
+        T = video_len if video_len is not None else self.video_length
+        _require_gpu(self.main[0].weight, type(self).__name__)
+        noise = self._draw_motion(num_samples, T)
+        _, rnn = self._param_list()
+        return _RnnLatentFn.apply(self, noise, num_samples, T, *rnn)
 
 
 # ==================================================================================================================

@@ -493,8 +493,8 @@ class GanTrainer:
         # freeze_gc: call freeze_host_gc() after the second iteration (process-global, hence opt-in; bench.py and
         # long training loops want it, see its docstring)
         self._iters, self._freeze_gc = 0, freeze_gc
-        # direct_grads: backward kernels write into a per-network GradArena (see its docstring); networks without
-        # the hook (the ODE-RNN generator) and CPU tensors keep the stock autograd accumulation
+        # direct_grads: backward kernels write into a per-network GradArena (see its docstring); CPU tensors (the gloo
+        # tests) and direct_grads=False keep the stock autograd accumulation + GradBucket
         self.arenas = {}
         if direct_grads:
             for m in (gen, dis_vid, dis_img):
@@ -518,6 +518,9 @@ class GanTrainer:
     def _begin(self, model, opt):
         a = self.arenas.get(id(model))
         if a is not None:
+            # (re)bind: the autograd nodes look the arena up on the module, and a second trainer built on the same
+            # networks (bench.py's graph-mode twin) would otherwise leave this trainer reducing an arena nobody writes
+            model._gode_arena = a
             a.begin()
         else:
             opt.zero_grad()
@@ -526,6 +529,9 @@ class GanTrainer:
         a = self.arenas.get(id(model))
         gscale = 1.0 / (self.world * nshards)
         if a is not None:
+            if getattr(model, "_gode_arena", None) is not a:
+                raise RuntimeError("another GanTrainer re-bound this network's gradient arena in the middle of an optimiser "
+                                   "step: the backward kernels wrote into its arena, not this one")
             a.end()
             if self.world > 1:       # the arena is the bucket: one collective, no packing copies
                 dist.all_reduce(a.flat, op=dist.ReduceOp.SUM, group=self.group)
@@ -693,6 +699,13 @@ class GanTrainer:
                                           f"({type(m).__name__} has none)")
         imgs = [t.detach().clone() for t in real_imgs]      # static inputs: later iterations are copied into them
         vids = [t.detach().clone() for t in real_vids]
+        # the graph must be self-contained with respect to the weights: every first-use pack of the iteration has to be
+        # recorded.  Which panels are "stale" is host-side state -- an eager sample_videos() between the warm-up
+        # iterations and this capture (or a load_state_dict / broadcast_state) would leave panels marked fresh, their
+        # pack launches would be missing from the graph, and every replay would run that network on panels that are
+        # never re-packed while Adam keeps moving the real weights.
+        for m in (self.gen, self.dis_vid, self.dis_img):
+            m.invalidate_packs()
         feed = self._feed = HostFeed(dev)
         self.gen._feed = feed
         for o in (self.gen_opt, self.vid_opt, self.img_opt):

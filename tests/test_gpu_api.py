@@ -248,6 +248,68 @@ def test_graph_replayed_iterations_are_bitwise_the_eager_ones():
     assert runs[0][3] == runs[1][3] == [12, 6]
 
 
+@pytest.mark.parametrize("odernn", [False, True])
+def test_graph_capture_is_self_contained_with_respect_to_weight_packs(odernn):
+    """Advisor r2: an eager sample_videos() between the last warm-up iteration and the capture iteration leaves the
+    generator's packed panels marked fresh; without the invalidation in _capture() the graph would hold no pack launch
+    for them and every replay would decode with the weights of iteration 2.  Eager passes between iteration index 1 and
+    2 (generator and discriminator), and a load_state_dict of perturbed weights between two replays: still bit-identical
+    to the eager schedule.  odernn=True: the same with the ODE-RNN generator, which now has a gradient arena and may be
+    captured."""
+    runs = []
+    for graph in (True, False):
+        seed_all(35)
+        gen, dv, di = G.build_mnist(ngf=16, ndf=16)
+        if odernn:
+            gen = G.VideoGeneratorMNISTODERNN(1, 50, 0, 16, 16, ngf=16)
+        gen.cuda(); dv.cuda(); di.cuda()
+        tr = G.GanTrainer(gen, dv, di, graph=graph)
+        rng = torch.Generator().manual_seed(12)
+        losses = []
+        for it in range(6):
+            imgs = [torch.rand(8, 1, 28, 28, generator=rng).cuda() for _ in range(2)]
+            vids = [torch.rand(8, 16, 1, 28, 28, generator=rng).cuda() for _ in range(2)]
+            if it == 2:                      # eager use right before the capture iteration
+                seed_all(78)
+                with torch.no_grad():
+                    v, _ = gen.sample_videos(3)
+                    dv(v); di(gen.sample_images(3)[0])
+            if it == 4:                      # weights replaced between two replays
+                for m in (gen, dv, di):
+                    sd = {k: (t + 0.01 if t.dtype == torch.float32 and "running" not in k else t) for k, t in m.state_dict().items()}
+                    m.load_state_dict(sd)
+            seed_all(500 + it)
+            losses.append([float(x) for x in tr.step(imgs, vids)])
+        torch.cuda.synchronize()
+        assert (tr._graph is not None) == graph
+        runs.append((losses, [t.detach().clone() for m in (gen, dv, di) for t in m.state_dict().values()]))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b)
+
+
+def test_second_trainer_on_the_same_networks_does_not_detach_the_first_ones_arenas():
+    """Advisor r2: GanTrainer.__init__ binds module._gode_arena; a second trainer on the same networks used to leave the
+    first one reducing an arena nobody writes.  Each trainer now re-binds its own arenas at the start of every optimiser
+    step: interleaved steps of two trainers fill the stepping trainer's arena (p.grad is a view of it)."""
+    seed_all(36)
+    gen, dv, di = G.build_mnist(ngf=8, ndf=8)
+    gen.cuda(); dv.cuda(); di.cuda()
+    tr1 = G.GanTrainer(gen, dv, di)
+    tr2 = G.GanTrainer(gen, dv, di)
+    x = torch.rand(4, 1, 28, 28).cuda()
+    v = torch.rand(4, 16, 1, 28, 28).cuda()
+    for tr in (tr1, tr2, tr1):
+        seed_all(37)
+        tr.d_image_step(x); tr.d_video_step(v); tr.g_step(4)
+        for m in (gen, dv, di):
+            a = tr.arenas[id(m)]
+            assert m._gode_arena is a
+            live = [p for p in m.parameters() if p.grad is not None]
+            assert live and all(p.grad.data_ptr() == a.views[p].data_ptr() for p in live)
+            assert float(a.flat.abs().sum()) > 0
+
+
 @pytest.mark.parametrize("which", ["video", "image"])
 def test_paired_discriminator_pass_equals_two_passes(which):
     """forward_pair(real, fake): ONE pass over [real; fake] with per-group BatchNorm statistics against the two separate

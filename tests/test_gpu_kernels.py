@@ -107,6 +107,10 @@ CASES = [
     (3, 32, (1, 40, 40), (1, 4, 4), (1, 2, 2), (0, 1, 1), 3),
     (2, 128, (2, 20, 96), (2, 3, 3), (1, 1, 2), (0, 1, 1), 2),
     (4, 32, (5, 18, 66), (3, 3, 3), (1, 2, 2), (1, 0, 1), 2),
+    # the patch kernel's tap-validity word holds 5 depth bits: kd = 5 is its last eligible depth (with a padded depth
+    # border), kd = 6 must fall back to the generic path (advisor r2: depth bits aliased the row bits there)
+    (3, 32, (7, 12, 40), (5, 2, 2), (1, 1, 1), (2, 1, 0), 2),
+    (3, 32, (8, 12, 40), (6, 2, 2), (1, 1, 1), (2, 1, 0), 2),
 ]
 
 
