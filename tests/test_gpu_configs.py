@@ -350,10 +350,13 @@ def test_config4_odernn_full_training_iteration_batch32_against_oracle():
 def test_motion_latent_gradients_kink_free_full_width(config):
     """The full-width generator pass of each config with every kink moved out of reach: BatchNorm beta = +6 (gamma = 1)
     puts all decoder pre-activations at x_hat + 6 > 0, so ReLU is the identity on every element and the loss -- a fixed
-    random linear functional of the frames, no discriminator -- is a smooth function of the parameters.  Two correct fp32
-    implementations must then agree to summation-order rounding: the motion-latent tensors (pre-net + ODEFunc, or
-    ODEFunc + GRU; the 16-entry vectors the noise-floor sentinel above is loose on) at 1e-4 max-norm, the decoder
-    weights at 2e-4 (long reductions, the tolerance of the kernel tests)."""
+    random linear functional of the frames, no discriminator -- is a smooth function of the parameters.  The head's
+    weights are scaled by 0.05: the head has no BatchNorm behind it to remove the 6 * sum(w) offset the shifted
+    activations carry, which otherwise saturates tanh for some seeds and leaves BOTH fp32 evaluations 2e-2 from the
+    float64 one (tests/diag/diag_odernn_kinkfree.py).  Two correct fp32 implementations must then agree to
+    summation-order rounding: EVERY generator tensor -- the motion-latent tensors (pre-net + ODEFunc, or ODEFunc + GRU;
+    the 16-entry vectors the noise-floor sentinel above is loose on) and the decoder weights -- at 1e-4 max-norm
+    (measured 1e-6 .. 1e-5)."""
     if config == "mnist":
         (gen, _, _), (ogen, _, _) = _mnist_pair(121)
         B = 32
@@ -368,6 +371,7 @@ def test_motion_latent_gradients_kink_free_full_width(config):
             for mod in m.main:
                 if isinstance(mod, torch.nn.BatchNorm2d):
                     mod.bias.fill_(6.0)
+            m.main[12].weight.mul_(0.05)
     seed_all(124)
     vid, _ = gen.sample_videos(B)
     img, _ = gen.sample_images(B)
@@ -380,12 +384,11 @@ def test_motion_latent_gradients_kink_free_full_width(config):
     ((rvid * wv).sum() + (rimg * wi).sum()).backward()
     assert rel_err(vid.detach().cpu(), rvid.detach()) < TOL and rel_err(img.detach().cpu(), rimg.detach()) < TOL
     ref = dict(ogen.named_parameters())
-    worst = {}
+    errs = {}
     for k, p in gen.named_parameters():
         if ref[k].grad is None:
             assert p.grad is None, k
             continue
-        e = rel_err(p.grad.cpu(), ref[k].grad)
-        worst[k] = e
-        latent = not k.startswith("main.")
-        assert e < (1e-4 if latent else 2e-4), (k, e, worst)
+        errs[k] = rel_err(p.grad.cpu(), ref[k].grad)
+    bad = {k: e for k, e in errs.items() if e >= 1e-4}
+    assert not bad, (bad, errs)
