@@ -82,14 +82,14 @@ class OdeRnnParams(C.Structure):
 class OdeRnnFwdOp(C.Structure):
     _fields_ = [("p", OdeRnnParams), ("noise", ptr), ("content", ptr), ("sel_t", ptr), ("z", ptr), ("hs", ptr),
                 ("hp", ptr), ("nsteps", ptr), ("N", i32), ("T", i32), ("rtol", f32), ("atol", f32), ("zcols", i32),
-                ("pad_", i32)]
+                ("pad_", i32), ("sync", ptr)]
     KIND = OP_ODERNN_FWD
 
 
 class OdeRnnBwdOp(C.Structure):
     _fields_ = [("p", OdeRnnParams), ("noise", ptr), ("hp", ptr), ("sel_t", ptr), ("gz", ptr), ("work", ptr),
                 ("grads", ptr), ("N", i32), ("T", i32), ("substeps", i32), ("accumulate", i32), ("zcols", i32),
-                ("pad_", i32), ("rtol", f32), ("atol", f32)]
+                ("pad_", i32), ("rtol", f32), ("atol", f32), ("sync", ptr), ("nsteps", ptr)]
     KIND = OP_ODERNN_BWD
 
 
@@ -128,7 +128,8 @@ _STRUCTS = {0: ConvGeom, OP_IGEMM: IgemmOp, OP_WGRAD: WgradOp, OP_BN_FINALIZE: B
 EXPORTS = ["gode_igemm", "gode_igemm_stats_rows", "gode_igemm_stats_rows0", "gode_igemm_work_size", "gode_pack_size", "gode_pack_weights", "gode_wgrad",
            "gode_wgrad_work_size", "gode_wgrad_auto_splits", "gode_bn_finalize", "gode_bn_bwd",
            "gode_bn_bwd_work_size", "gode_bn_apply", "gode_col2im", "gode_ode_fwd", "gode_ode_bwd", "gode_ode_bwd_work_size", "gode_odernn_fwd",
-           "gode_odernn_bwd", "gode_odernn_bwd_work_size", "gode_bce_logits",
+           "gode_odernn_bwd", "gode_odernn_bwd_work_size", "gode_odernn_sync_size", "gode_odernn_fwd_multi",
+           "gode_odernn_bwd_multi", "gode_bce_logits",
            "gode_adam_l2", "gode_adam_multi", "gode_adam_multi_dev", "gode_scale", "gode_run", "gode_version", "gode_sizeof"]
 
 _lib = None
@@ -170,6 +171,10 @@ def lib():
     L.gode_ode_bwd_work_size.restype = i64
     L.gode_odernn_bwd_work_size.argtypes = [i32]
     L.gode_odernn_bwd_work_size.restype = i64
+    L.gode_odernn_sync_size.argtypes = [i32]
+    L.gode_odernn_sync_size.restype = i64
+    L.gode_odernn_fwd_multi.argtypes = [ptr, i32, ptr]
+    L.gode_odernn_bwd_multi.argtypes = [ptr, i32, ptr]
     L.gode_scale.argtypes = [ptr, ptr, i64, f32, C.c_int, ptr]
     L.gode_adam_multi.argtypes = [ptr, i32, i64, f32, f32, f32, f32, f32, f32, i32, ptr]
     L.gode_adam_multi_dev.argtypes = [ptr, i32, i64, f32, f32, f32, f32, f32, ptr, ptr]

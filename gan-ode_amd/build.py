@@ -7,8 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgode.so")
-SOURCES = ["igemm.hip", "conv_patch.hip", "wgrad.hip", "ode.hip", "ode_valu.hip", "odernn.hip", "adj_adaptive.hip", "elementwise.hip", "api.hip"]
-HEADERS = ["common.h", "conv_geom.h", "ode_common.h", os.path.join("..", "..", "include", "gode.h")]
+SOURCES = ["igemm.hip", "conv_patch.hip", "wgrad.hip", "ode.hip", "ode_valu.hip", "odernn.hip", "odernn_valu.hip", "adj_adaptive.hip", "elementwise.hip", "api.hip"]
+HEADERS = ["common.h", "conv_geom.h", "ode_common.h", "valu_common.h", os.path.join("..", "..", "include", "gode.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 
 

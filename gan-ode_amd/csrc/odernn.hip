@@ -2,15 +2,15 @@
 //   h_0 ~ N(0,1);  per frame:  h' = odeint_adjoint(ODEFunc, h, [0,1])[-1]  (torchdiffeq default: dopri5, rtol 1e-7,
 //   atol 1e-9),  h = GRUCell(e_t, h'),  e_t ~ N(0,1);  latent row t = h_{t+1}.
 //
-// Forward: one launch for all T frames.  dopri5 with torchdiffeq's controller (initial step selection, accept iff
-// RMS(err/tol) <= 1, factor clipping 0.2..10, safety 0.9, 4th-order dense output at t = 1), the error norm taken
-// JOINTLY over all trajectories of the workgroup (up to 64; torchdiffeq takes it over the whole batch, which is the
-// same thing at the reference batch of 32).  Every 16x16
-// product (ODEFunc and the six GRU gate products) is a chained v_mfma_f32_16x16x4_f32 tile as in ode.hip.
-// Backward: GRU backward + continuous adjoint of each unit-interval solve.  torchdiffeq integrates the adjoint
-// adaptively to the same 1e-7 tolerance; here it is integrated with `substeps` fixed reverse-time Kutta-3/8 steps
-// (default 32: 4th-order error ~1e-6 relative, far inside the 2e-4 gradient tolerance) -- a recorded deviation in
-// HOW the same continuous adjoint is discretised, not in what is computed.
+// These are the MFMA-chain kernels of rounds 1-2 (16 trajectories per wave, every 16x16 product a chained
+// v_mfma_f32_16x16x4_f32 tile as in ode.hip).  Since round 3 the default kernels are odernn_valu.hip (VALU/DPP mapping,
+// whole-batch error norm, several solves per launch); what remains in use from this file:
+//   * odernn_fwd_kernel: the forward fallback above GODE_ODERNN_SYNC_MAX_N trajectories per launch (error norm per
+//     64-trajectory workgroup instead of the whole batch: the one recorded deviation, unused by any configuration);
+//   * odernn_bwd_kernel: the adjoint discretised with `substeps` FIXED reverse-time Kutta-3/8 steps per frame
+//     (gode_odernn_bwd_op.substeps > 0; 32 steps agree with the adaptive adjoint to ~1e-6) -- an option, not the default:
+//     the default (substeps == 0) integrates the adjoint adaptively with torchdiffeq's mixed norm, as odeint_adjoint does;
+//   * ode_dopri5_fwd_kernel: dopri5 for the plain Neural-ODE generators (gode_ode_fwd_op.method == 1).
 #include "ode_common.h"
 
 // trajectories per workgroup of the forward kernel (4 waves): keeps the kernel inside the register file -- a spilling
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(RNN_BLOCK_SAMPLES * 4) odernn_fwd_kernel(const
       else { fac = 0.9f * powf(ratio, -0.2f); fac = fminf(10.f, fmaxf(fac, ratio < 1.f ? 1.f : 0.2f)); }
       dtd *= (double)fac;
     }
-    if (a.nsteps && threadIdx.x == 0) a.nsteps[blockIdx.x * T + t] = steps;
+    if (a.nsteps && threadIdx.x == 0 && blockIdx.x == 0) a.nsteps[t] = steps;
     if (valid && a.hp) *reinterpret_cast<f32x4*>(a.hp + ((int64_t)n * T + t) * 16 + 4 * g) = yend;
     // ---- GRUCell(e_t, h')
     const f32x4 e = valid ? ld4(a.noise + ((int64_t)(t + 1) * a.N + n) * 16 + 4 * g) : zero4();
@@ -275,11 +275,7 @@ int gode_launch_ode_dopri5(const gode_ode_fwd_op* op, hipStream_t st) {
   return 0;
 }
 
-extern "C" int gode_odernn_fwd(const gode_odernn_fwd_op* op, void* stream) {
-  if (!op || !op->noise || !op->z || op->N <= 0 || op->T < 1 || !(op->rtol > 0.f) || !(op->atol >= 0.f)) return GODE_E_ARG;
-  if (op->zcols < 68 || op->zcols % 4 != 0) return GODE_E_ARG;
-  if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2 || !op->p.Wih || !op->p.Whh || !op->p.bih || !op->p.bhh) return GODE_E_ARG;
-  hipStream_t st = (hipStream_t)stream;
+int gode_launch_odernn_fwd_mfma(const gode_odernn_fwd_op* op, hipStream_t st) {
   if (op->content) {
     const int rows_per = op->sel_t ? 1 : op->T;
     int64_t total4 = (int64_t)op->N * rows_per * ((op->zcols - 16) >> 2);
@@ -413,18 +409,12 @@ __global__ void __launch_bounds__(256) odernn_bwd_reduce_kernel(const float* wor
   grads[i] = accumulate ? grads[i] + sacc : sacc;
 }
 
-extern "C" int64_t gode_odernn_bwd_work_size(int32_t N) { return (int64_t)((N + 15) / 16) * RNN_NPARAM; }
-
 int gode_launch_odernn_bwd_adaptive(const gode_odernn_bwd_op* op, hipStream_t st);   // adj_adaptive.hip
 
-extern "C" int gode_odernn_bwd(const gode_odernn_bwd_op* op, void* stream) {
-  if (!op || !op->noise || !op->hp || !op->gz || !op->work || !op->grads || op->N <= 0 || op->T < 1 || op->substeps < 0)
-    return GODE_E_ARG;
-  if (op->substeps == 0 && (!(op->rtol > 0.f) || !(op->atol >= 0.f))) return GODE_E_ARG;
-  if (op->zcols < 16 || op->zcols % 4 != 0) return GODE_E_ARG;
-  if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2 || !op->p.Wih || !op->p.Whh || !op->p.bih || !op->p.bhh) return GODE_E_ARG;
+// substeps > 0: fixed Kutta-3/8 substeps; substeps == 0: the MFMA adaptive adjoint (norm per 64-trajectory workgroup), only
+// reached above the co-residency limit of odernn_valu.hip
+int gode_launch_odernn_bwd_mfma(const gode_odernn_bwd_op* op, hipStream_t st) {
   const int nblk = (op->N + 15) / 16;
-  hipStream_t st = (hipStream_t)stream;
   if (op->substeps == 0) {
     const int rc = gode_launch_odernn_bwd_adaptive(op, st);
     if (rc) return rc;

@@ -670,8 +670,13 @@ class _RnnGenPlan(_GenPlan):
         f32 = dict(dtype=torch.float32, device=self.device)
         self.noise = self.x        # [T+1, n, 16]: h_0 and the per-frame GRU inputs (staged by the base class)
         self.hp = torch.empty(n_traj, T, 16, **f32)
-        self.nsteps = torch.zeros((n_traj + 63) // 64 * T, dtype=torch.int32, device=self.device)
+        self.nsteps = torch.zeros(T, dtype=torch.int32, device=self.device)          # dopri5 trial steps per frame
+        self.nsteps_bwd = torch.zeros(T, dtype=torch.int32, device=self.device)      # ... of each frame's adjoint call
         self.rnn_work = torch.empty(L.lib().gode_odernn_bwd_work_size(n_traj), **f32)
+        # more than one workgroup (32 trajectories each): the whole-batch error norm is exchanged through these words
+        ns = L.lib().gode_odernn_sync_size(n_traj)
+        self.sync_f = torch.zeros(ns, dtype=torch.int32, device=self.device) if ns else None
+        self.sync_b = torch.zeros(ns, dtype=torch.int32, device=self.device) if ns else None
 
     @staticmethod
     def _x_shape(n_traj, T):
@@ -689,11 +694,13 @@ class _RnnGenPlan(_GenPlan):
             op = L.OdeRnnParams(*ptrs)
             self.fwd_op = L.OdeRnnFwdOp(p=op, noise=dptr(self.noise), content=dptr(self.content), sel_t=dptr(self.sel),
                                         z=dptr(self.stack.x_in), hs=None, hp=dptr(self.hp), nsteps=dptr(self.nsteps),
-                                        N=self.n, T=self.T, rtol=self.gen.ode_rtol, atol=self.gen.ode_atol, zcols=Z_COLS)
+                                        N=self.n, T=self.T, rtol=self.gen.ode_rtol, atol=self.gen.ode_atol, zcols=Z_COLS,
+                                        sync=dptr(self.sync_f))
             self.bwd_op = L.OdeRnnBwdOp(p=op, noise=dptr(self.noise), hp=dptr(self.hp), sel_t=dptr(self.sel), gz=None,
                                         work=dptr(self.rnn_work), grads=None, N=self.n, T=self.T,
                                         substeps=self.gen.adjoint_substeps, accumulate=0, zcols=Z_COLS,
-                                        rtol=self.gen.ode_rtol, atol=self.gen.ode_atol)
+                                        rtol=self.gen.ode_rtol, atol=self.gen.ode_atol, sync=dptr(self.sync_b),
+                                        nsteps=dptr(self.nsteps_bwd))
             self.fwd_prog = L.Program([self.fwd_op])
         self.fwd_op.rtol, self.fwd_op.atol = self.gen.ode_rtol, self.gen.ode_atol
         self.bwd_op.rtol, self.bwd_op.atol = self.gen.ode_rtol, self.gen.ode_atol
@@ -737,18 +744,20 @@ class _RnnLatentFn(torch.autograd.Function):
         noise = noise_host.to(dev)                                    # [T+1, n, 16]: h_0, e_1 .. e_T
         hp = torch.empty(n, T, 16, **f32)
         z = torch.empty(n * T, 68, **f32)                             # the kernel's latent-row layout; columns 0..15 used
-        nsteps = torch.zeros((n + 63) // 64 * T, dtype=torch.int32, device=dev)
+        nsteps = torch.zeros(T, dtype=torch.int32, device=dev)
+        ns = L.lib().gode_odernn_sync_size(n)
+        sync = torch.zeros(ns, dtype=torch.int32, device=dev) if ns else None
         prm = L.OdeRnnParams(*[dptr(p) for p in params])
         fop = L.OdeRnnFwdOp(p=prm, noise=dptr(noise), content=None, sel_t=None, z=dptr(z), hs=None, hp=dptr(hp),
-                            nsteps=dptr(nsteps), N=n, T=T, rtol=gen.ode_rtol, atol=gen.ode_atol, zcols=68)
+                            nsteps=dptr(nsteps), N=n, T=T, rtol=gen.ode_rtol, atol=gen.ode_atol, zcols=68, sync=dptr(sync))
         L.run_one(fop, stream_ptr())
-        ctx.keep = (gen, noise, hp, n, T, [p.detach() for p in params])
+        ctx.keep = (gen, noise, hp, n, T, [p.detach() for p in params], sync)
         ctx.nsteps = nsteps
         return z[:, :16].contiguous()
 
     @staticmethod
     def backward(ctx, gout):
-        gen, noise, hp, n, T, params = ctx.keep
+        gen, noise, hp, n, T, params, sync = ctx.keep
         dev = noise.device
         g = gout.contiguous()
         grads = torch.empty(L.ODERNN_NPARAM, dtype=torch.float32, device=dev)
@@ -756,7 +765,7 @@ class _RnnLatentFn(torch.autograd.Function):
         prm = L.OdeRnnParams(*[dptr(p) for p in params])
         bop = L.OdeRnnBwdOp(p=prm, noise=dptr(noise), hp=dptr(hp), sel_t=None, gz=dptr(g), work=dptr(work),
                             grads=dptr(grads), N=n, T=T, substeps=gen.adjoint_substeps, accumulate=0, zcols=16,
-                            rtol=gen.ode_rtol, atol=gen.ode_atol)
+                            rtol=gen.ode_rtol, atol=gen.ode_atol, sync=dptr(sync))
         L.run_one(bop, stream_ptr())
         return (None, None, None, None, *[grads[o:o + k].view(shp) for o, k, shp in _RNN_GRAD_OFFS])
 

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GODE_VERSION 101
+#define GODE_VERSION 102
 
 enum { GODE_OK = 0, GODE_E_ARG = -1, GODE_E_SHAPE = -2, GODE_E_KIND = -3 };
 enum { GODE_ACT_NONE = 0, GODE_ACT_RELU = 1, GODE_ACT_LRELU = 2,              /* LeakyReLU slope is 0.2 */
@@ -212,10 +212,17 @@ int64_t gode_ode_bwd_work_size(int32_t N);
 #define GODE_ODE_NPARAM 2672
 
 /* ---- ODE-RNN motion latent (models/mocogan_ode_rnn.py:41-53) -------------------------------
- * per frame: h' = odeint_adjoint(ODEFunc, h, [0,1])[-1] with torchdiffeq's default dopri5 (rtol, atol; error norm
- * joint over the trajectories of a workgroup, <= 64), h = GRUCell(e_t, h').  noise[T+1][N][16] = h_0, e_0..e_{T-1}
- * drawn on the host.  z / content / sel_t as in gode_ode_fwd (row t = h_{t+1}).  hs[N][T+1][16], hp[N][T][16]
- * (post-ODE states) are kept for the backward; nsteps[ceil(N/64)][T] (nullable) counts dopri5 trial steps. */
+ * per frame: h' = odeint_adjoint(ODEFunc, h, [0,1])[-1] with torchdiffeq's default dopri5 (rtol, atol), then
+ * h = GRUCell(e_t, h').  noise[T+1][N][16] = h_0, e_0..e_{T-1} drawn on the host.  z / content / sel_t as in
+ * gode_ode_fwd (row t = h_{t+1}).  hs[N][T+1][16] (nullable), hp[N][T][16] (post-ODE states, kept for the backward).
+ * Error norm: the RMS over ALL N trajectories of the call, as torchdiffeq takes it (models/mocogan_ode_rnn.py:47-48 hands
+ * the whole batch to one odeint call): a workgroup integrates 32 trajectories; for N > 32 the workgroups of a call
+ * exchange their partial sums of squares through `sync` (gode_odernn_sync_size(N) 4-byte words, caller-owned, zeroed by
+ * the launch) and add them in fixed order, so every workgroup takes bit-identical accept / reject decisions and re-runs
+ * are bit-identical.  All workgroups of a launch must be co-resident: N <= GODE_ODERNN_SYNC_MAX_N per launch (summed
+ * over the ops of a _multi launch); above that the call falls back to one norm per 64-trajectory workgroup (a recorded
+ * deviation, unused by any configuration).  nsteps[T] (nullable): dopri5 trial steps per frame (of workgroup 0 in the
+ * fallback); a negative entry reports a solve that hit the trial-step limit or whose step size underflowed. */
 typedef struct gode_odernn_params {
   const float* W1; const float* b1; const float* W2; const float* b2;         /* ODEFunc */
   const float* Wih; const float* Whh; const float* bih; const float* bhh;     /* GRUCell(16,16): [48,16]x2, [48]x2 */
@@ -225,21 +232,35 @@ typedef struct gode_odernn_fwd_op {
   const float* noise; const float* content; const int32_t* sel_t;
   float* z; float* hs; float* hp; int32_t* nsteps;
   int32_t N, T; float rtol, atol; int32_t zcols, pad_;
+  int32_t* sync;    /* N > 32: >= gode_odernn_sync_size(N) words; ignored (may be NULL) for N <= 32 */
 } gode_odernn_fwd_op;
 int gode_odernn_fwd(const gode_odernn_fwd_op* op, void* stream);
+#define GODE_ODERNN_SYNC_MAX_N 4096
+int64_t gode_odernn_sync_size(int32_t N);
+/* `count` (<= 8) independent solves in ONE launch, each with its own whole-batch norm: one training iteration's
+ * sample_videos / sample_images latents depend only on the generator's weights at the start of the iteration, so their
+ * one-workgroup solves run side by side on different CUs instead of back to back (ops: HOST array). */
+int gode_odernn_fwd_multi(const gode_odernn_fwd_op* ops, int32_t count, void* stream);
 /* backward: GRU backward + continuous adjoint of every unit-interval solve.  substeps == 0 (what the Python side
  * uses): integrated ADAPTIVELY as torchdiffeq does -- per frame one adjoint call, dopri5 (rtol, atol) on the augmented
- * state (y, a, g_theta), mixed norm joint over a workgroup's <= 64 trajectories.  substeps > 0: `substeps` fixed
- * reverse-time Kutta-3/8 steps per frame (32 agree with the adaptive result to ~1e-6).
- * grads: 2176 floats = W1,b1,W2,b2,Wih,Whh,bih,bhh.  work >= gode_odernn_bwd_work_size floats. */
+ * state (y, a, g_theta), mixed norm (max over the RMS norms of y, a and each ODEFunc parameter tensor) over the whole
+ * batch of the call (sync as above).  substeps > 0: `substeps` fixed reverse-time Kutta-3/8 steps per frame (32 agree
+ * with the adaptive result to ~1e-6).  grads: 2176 floats = W1,b1,W2,b2,Wih,Whh,bih,bhh.
+ * work >= gode_odernn_bwd_work_size floats.  nsteps[T] (nullable, adaptive only): trial steps per frame's adjoint call,
+ * negative = the solve stalled (trial-step limit / step-size underflow; torchdiffeq asserts there). */
 typedef struct gode_odernn_bwd_op {
   gode_odernn_params p;
   const float* noise; const float* hp; const int32_t* sel_t; const float* gz;
   float* work; float* grads; int32_t N, T, substeps, accumulate, zcols, pad_;
   float rtol, atol;   /* substeps == 0: adaptive adjoint (dopri5 on (y, a, g_theta) per frame, mixed norm), as torchdiffeq */
+  int32_t* sync;      /* as in gode_odernn_fwd_op (adaptive adjoint with N > 32) */
+  int32_t* nsteps;
 } gode_odernn_bwd_op;
 int gode_odernn_bwd(const gode_odernn_bwd_op* op, void* stream);
 int64_t gode_odernn_bwd_work_size(int32_t N);
+/* the adjoints of `count` (<= 8) independent solves (the video and the image path of one generator step) in one launch;
+ * every op reduces into its own grads (accumulate as given, ops are reduced in array order) */
+int gode_odernn_bwd_multi(const gode_odernn_bwd_op* ops, int32_t count, void* stream);
 #define GODE_ODERNN_NPARAM 2176
 
 /* ---- loss and optimiser (mnist_moco_ode.py:86-89) ------------------------------------------------------------

@@ -29,12 +29,17 @@ def test_odernn_kernels_against_oracle(N, T):
     f = M.OdeRhs(16, 16)
     gru = torch.nn.GRUCell(16, 16)
     noise = torch.randn(T + 1, N, 16)
-    # oracle
+    # oracle; the right-hand side counts its evaluations: a dopri5 call makes 2 (initial step selection) + 6 per trial step
+    calls = [0]
+    f.register_forward_pre_hook(lambda *_: calls.__setitem__(0, calls[0] + 1))
     h = [noise[0]]
     hps = []
+    ref_trials = []
     t01 = torch.tensor([0.0, 1.0])
     for t in range(T):
+        c0 = calls[0]
         hp = ode_ref.odeint_adjoint(f, h[-1], t01)[-1]
+        ref_trials.append((calls[0] - c0 - 2) // 6)
         hps.append(hp)
         h.append(gru(noise[t + 1], hp))
     zref = torch.stack(h[1:], dim=1)                       # [N, T, 16]
@@ -47,9 +52,12 @@ def test_odernn_kernels_against_oracle(N, T):
     nz, content = noise.cuda(), torch.randn(N, 50).cuda()
     z = torch.full((N * T, 72), float("nan"), device="cuda")
     hp_d = torch.empty(N, T, 16, device="cuda")
-    nst = torch.zeros((N + 63) // 64 * T, dtype=torch.int32, device="cuda")
+    nst = torch.full((T,), -7, dtype=torch.int32, device="cuda")
+    nsync = L.lib().gode_odernn_sync_size(N)
+    sync = torch.zeros(max(nsync, 1), dtype=torch.int32, device="cuda")
     fop = L.OdeRnnFwdOp(p=op, noise=nz.data_ptr(), content=content.data_ptr(), sel_t=None, z=z.data_ptr(), hs=None,
-                        hp=hp_d.data_ptr(), nsteps=nst.data_ptr(), N=N, T=T, rtol=1e-7, atol=1e-9, zcols=72)
+                        hp=hp_d.data_ptr(), nsteps=nst.data_ptr(), N=N, T=T, rtol=1e-7, atol=1e-9, zcols=72,
+                        sync=sync.data_ptr() if nsync else None)
     L.run_one(fop, stream())
     zz = z.cpu().view(N, T, 72)
     assert rel_err(hp_d.cpu(), torch.stack(hps, dim=1).detach()) < 2e-5
@@ -57,15 +65,26 @@ def test_odernn_kernels_against_oracle(N, T):
     assert torch.equal(zz[:, :, 16:66], content.cpu()[:, None, :].expand(N, T, 50)) and float(zz[:, :, 66:].abs().max()) == 0
     steps = nst.cpu()
     assert int(steps.min()) >= 2 and int(steps.max()) < 200, steps      # the controller converges in a handful of steps
+    # whole-batch error norm (also across the 10 workgroups of N = 300): the device takes the oracle's step sequence
+    # (an accept / reject decision within rounding of ratio = 1 may fall either way in two fp32 evaluations -- at rtol 1e-7 the
+    # error estimate is a few ulps of the state: measured, one frame of the N = 20 case takes 6 trial steps where the oracle takes 7)
+    diff = [abs(a - b) for a, b in zip(steps.tolist(), ref_trials)]
+    assert max(diff) <= 1 and sum(1 for d in diff if d) <= max(1, T // 8), (steps.tolist(), ref_trials)
     gz = torch.zeros(N * T, 72, device="cuda")
     gz.view(N, T, 72)[:, :, :16] = gup.cuda()
     grads = torch.full((L.ODERNN_NPARAM,), float("nan"), device="cuda")
     work = torch.empty(L.lib().gode_odernn_bwd_work_size(N), device="cuda")
+    nstb = torch.full((T,), -7, dtype=torch.int32, device="cuda")
+    syncb = torch.zeros(max(nsync, 1), dtype=torch.int32, device="cuda")
     for substeps, tol in ((0, 1e-4), (32, 1e-4)):       # 0: adaptive adjoint (what torchdiffeq does); 32: fixed Kutta-3/8
         grads.fill_(float("nan"))
         bop = L.OdeRnnBwdOp(p=op, noise=nz.data_ptr(), hp=hp_d.data_ptr(), sel_t=None, gz=gz.data_ptr(), work=work.data_ptr(),
-                            grads=grads.data_ptr(), N=N, T=T, substeps=substeps, accumulate=0, zcols=72, rtol=1e-7, atol=1e-9)
+                            grads=grads.data_ptr(), N=N, T=T, substeps=substeps, accumulate=0, zcols=72, rtol=1e-7, atol=1e-9,
+                            sync=syncb.data_ptr() if nsync else None, nsteps=nstb.data_ptr())
         L.run_one(bop, stream())
+        if substeps == 0:
+            sb = nstb.cpu()
+            assert int(sb.min()) >= 2 and int(sb.max()) < 400, sb        # no stalled call (those report negative counts)
         g = grads.cpu()
         off = 0
         for name, r in zip(("W1", "b1", "W2", "b2", "Wih", "Whh", "bih", "bhh"), ref_grads):
