@@ -697,7 +697,7 @@ struct AdjV {
   }
 };
 
-struct RnnBwdJobs { gode_odernn_bwd_op op[RV_MAX_JOBS]; int32_t nblk[RV_MAX_JOBS]; int32_t count; };
+struct RnnBwdJobs { gode_odernn_bwd_op op[RV_MAX_JOBS]; int32_t nblk[RV_MAX_JOBS]; int32_t count; int32_t direct; };
 
 __global__ void __launch_bounds__(RV_THREADS) odernn_bwd_valu_kernel(const RnnBwdJobs J) {
   __shared__ float P[TH_N + 96];       // W1, b1, W2, b2 (gradient-vector order), bih, bhh
@@ -809,10 +809,11 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_bwd_valu_kernel(const RnnBw
     gth[0] += S.gt[0]; gth[1] += S.gt[1];
     carry = adj;                                                                 // dL/dh_t
   }
-  // ---- output: one workgroup writes (or adds to) grads directly; several write one row of `work` each (the ODEFunc block
-  // holds the BATCH total in every workgroup: row 0 carries it, the other rows carry zeros) for odernn_bwd_rows_kernel
-  float* out = S.X.nwg == 1 ? a.grads : a.work + (int64_t)wg * RO_N;
-  const bool direct_acc = S.X.nwg == 1 && a.accumulate;
+  // ---- output: a launch of ONE workgroup writes (or adds to) grads directly; otherwise every workgroup writes one row of
+  // its op's `work` (the ODEFunc block holds the BATCH total in every workgroup of an op: row 0 carries it, the other rows
+  // carry zeros) and odernn_bwd_rows_kernel adds the rows in fixed order
+  float* out = J.direct ? a.grads : a.work + (int64_t)wg * RO_N;
+  const bool direct_acc = J.direct && a.accumulate;
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -831,13 +832,15 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_bwd_valu_kernel(const RnnBw
   }
 }
 
-// rows of `work` (one per workgroup) -> grads, fixed order
-__global__ void __launch_bounds__(256) odernn_bwd_rows_kernel(const float* work, float* grads, int rows, int accumulate) {
+// rows of `work` (one per workgroup; the ops that share a grads pointer, in array order) -> grads, fixed order
+struct RowsArgs { const float* work[RV_MAX_JOBS]; int32_t rows[RV_MAX_JOBS]; int32_t count, accumulate; float* grads; };
+__global__ void __launch_bounds__(256) odernn_bwd_rows_kernel(const RowsArgs A) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= RO_N) return;
   float s = 0.f;
-  for (int b = 0; b < rows; ++b) s += work[(int64_t)b * RO_N + k];
-  grads[k] = accumulate ? grads[k] + s : s;
+  for (int j = 0; j < A.count; ++j)
+    for (int b = 0; b < A.rows[j]; ++b) s += A.work[j][(int64_t)b * RO_N + k];
+  A.grads[k] = A.accumulate ? A.grads[k] + s : s;
 }
 
 int gode_launch_odernn_bwd_mfma(const gode_odernn_bwd_op* op, hipStream_t st);   // odernn.hip: fixed substeps / fallback
@@ -853,40 +856,57 @@ static bool rnn_bwd_args_ok(const gode_odernn_bwd_op* op) {
 
 extern "C" int64_t gode_odernn_bwd_work_size(int32_t N) { return (int64_t)((N + 15) / 16) * RO_N; }
 
-extern "C" int gode_odernn_bwd_multi(const gode_odernn_bwd_op* ops, int32_t count, void* stream) {
-  if (!ops || count < 1 || count > RV_MAX_JOBS) return GODE_E_ARG;
-  hipStream_t st = (hipStream_t)stream;
+static int rnn_bwd_launch(const gode_odernn_bwd_op* ops, int count, hipStream_t st) {
   RnnBwdJobs J;
-  J.count = 0;
-  int spinning = 0;
-  for (int k = 0; k < count; ++k) {
-    if (!rnn_bwd_args_ok(&ops[k])) return GODE_E_ARG;
-    const int nblk = (ops[k].N + RV_TRAJ - 1) / RV_TRAJ;
-    if (ops[k].substeps == 0 && nblk > 1) spinning += nblk;
-  }
+  J.count = count;
+  int grid = 0;
   for (int k = 0; k < count; ++k) {
     const int nblk = (ops[k].N + RV_TRAJ - 1) / RV_TRAJ;
-    if (ops[k].substeps > 0 || (spinning > RV_MAX_WGS && nblk > 1)) {
-      const int rc = gode_launch_odernn_bwd_mfma(&ops[k], st);     // fixed Kutta-3/8 substeps, or above the co-residency limit
-      if (rc) return rc;
-      continue;
-    }
     if (nblk > 1) {
       const hipError_t e = hipMemsetAsync(ops[k].sync, 0, XS_HDR * sizeof(int32_t), st);
       if (e != hipSuccess) return (int)e;
     }
-    J.op[J.count] = ops[k]; J.nblk[J.count] = nblk; J.count += 1;
+    J.op[k] = ops[k]; J.nblk[k] = nblk;
+    grid += nblk;
   }
-  if (J.count == 0) return 0;
-  int grid = 0;
-  for (int k = 0; k < J.count; ++k) grid += J.nblk[k];
+  J.direct = (count == 1 && grid == 1) ? 1 : 0;
   hipLaunchKernelGGL(odernn_bwd_valu_kernel, dim3(grid), dim3(RV_THREADS), 0, st, J);
   GODE_LAUNCH_CHECK();
-  for (int k = 0; k < J.count; ++k) {
-    if (J.nblk[k] > 1) {
-      hipLaunchKernelGGL(odernn_bwd_rows_kernel, dim3((RO_N + 255) / 256), dim3(256), 0, st, J.op[k].work, J.op[k].grads, J.nblk[k], J.op[k].accumulate);
-      GODE_LAUNCH_CHECK();
+  if (J.direct) return 0;
+  bool done[RV_MAX_JOBS] = {false};
+  for (int k = 0; k < count; ++k) {
+    if (done[k]) continue;
+    RowsArgs A;
+    A.count = 0; A.grads = ops[k].grads; A.accumulate = ops[k].accumulate;     // later ops of the group add by construction
+    for (int j = k; j < count; ++j) {
+      if (!done[j] && ops[j].grads == ops[k].grads) { A.work[A.count] = ops[j].work; A.rows[A.count] = J.nblk[j]; A.count += 1; done[j] = true; }
     }
+    hipLaunchKernelGGL(odernn_bwd_rows_kernel, dim3((RO_N + 255) / 256), dim3(256), 0, st, A);
+    GODE_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int gode_odernn_bwd_multi(const gode_odernn_bwd_op* ops, int32_t count, void* stream) {
+  if (!ops || count < 1 || count > RV_MAX_JOBS) return GODE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int spinning = 0;
+  bool fallback = false;
+  for (int k = 0; k < count; ++k) {
+    if (!rnn_bwd_args_ok(&ops[k])) return GODE_E_ARG;
+    const int nblk = (ops[k].N + RV_TRAJ - 1) / RV_TRAJ;
+    if (ops[k].substeps > 0) fallback = true;
+    else if (nblk > 1) spinning += nblk;
+  }
+  if (spinning > RV_MAX_WGS) fallback = true;
+  if (!fallback) return rnn_bwd_launch(ops, count, st);
+  // fixed Kutta-3/8 substeps, or more spinning workgroups than are guaranteed co-resident: the ops run one after the other
+  // in array order (each with its own accumulate flag), the affected ones on the MFMA kernels of odernn.hip
+  for (int k = 0; k < count; ++k) {
+    const int nblk = (ops[k].N + RV_TRAJ - 1) / RV_TRAJ;
+    const bool mfma = ops[k].substeps > 0 || (nblk > 1 && spinning > RV_MAX_WGS);
+    const int rc = mfma ? gode_launch_odernn_bwd_mfma(&ops[k], st) : rnn_bwd_launch(&ops[k], 1, st);
+    if (rc) return rc;
   }
   return 0;
 }

@@ -239,7 +239,8 @@ class _GenPlan:
         if self.gen.ode_method == "dopri5":
             self.bwd_op.substeps = self.gen.adjoint_substeps
 
-    def forward(self, x_host, content_host, sel_host, training, keep):
+    def stage_inputs(self, x_host, content_host, sel_host):
+        """Host-drawn inputs -> the plan's device block, on the current stream (one H2D copy)."""
         self._programs()
         feed = getattr(self.gen, "_feed", None)
         if feed is not None and feed.recording:
@@ -259,7 +260,16 @@ class _GenPlan:
             if slot["ev"] is None:
                 slot["ev"] = torch.cuda.Event()
             slot["ev"].record()
-        out = self.stack.forward(training, pre_ops_program=self.fwd_prog)
+
+    def forward(self, x_host, content_host, sel_host, training, keep):
+        """x_host None: the latent rows of this call were produced ahead of time by VideoGenerator.prefetch_latents (on
+        its own stream); only the decoder runs here, after the latent's event."""
+        if x_host is None:
+            torch.cuda.current_stream().wait_event(self._latent_ev)
+            out = self.stack.forward(training)
+        else:
+            self.stage_inputs(x_host, content_host, sel_host)
+            out = self.stack.forward(training, pre_ops_program=self.fwd_prog)
         self.busy = keep
         return out
 
@@ -509,6 +519,7 @@ class VideoGenerator(nn.Module):
             self._pool.clear()   # parameter storage may have moved
             self.__dict__.pop("_labels", None)
             self.__dict__.pop("_latent_plans", None)
+            self.__dict__.pop("_prefetched", None)
         return r
 
     def invalidate_packs(self):
@@ -542,13 +553,77 @@ class VideoGenerator(nn.Module):
         x = torch.randn(num_samples, self.dim_z_motion)
         return torch.from_numpy(content), x
 
-    def _run(self, n_traj, T, select, x, content, sel):
+    def _run(self, n_traj, T, select, x, content, sel, plan=None):
         _require_gpu(self.main[0].weight, type(self).__name__)
-        plan = self._pool.get((n_traj, T, select), lambda: self._plan_cls(self, n_traj, T, select))
+        if plan is None:
+            plan = self._pool.get((n_traj, T, select), lambda: self._plan_cls(self, n_traj, T, select))
         dec, ode = self._param_list()
         # (grad mode is off inside Function.forward, so decide here whether the plan must be kept for a backward)
         keep = torch.is_grad_enabled() and any(p.requires_grad for p in dec + ode)
         return _GenFn.apply(plan, x, content, sel, self.training, keep, len(dec), *dec, *ode)
+
+    # -- latents ahead of time ----------------------------------------------------------------------------------------
+    def prefetch_latents(self, calls):
+        """calls: [("videos" | "images", num_samples), ...] -- the sample_videos / sample_images calls that will follow,
+        in order, with no optimiser step on THIS network in between (one training iteration: the generator's weights
+        change only at its end).  All host draws are made now, in call order (the same NumPy / torch CPU generator
+        consumption as the calls themselves would make), and the latent solves of all calls are issued at once on a side
+        stream; the calls then only wait for the latents and run the decoder.  For the ODE-RNN generator the solves --
+        one workgroup of a 256-CU GPU each, ~100 us of dependent arithmetic -- become ONE launch whose workgroups run side
+        by side (gode_odernn_fwd_multi) instead of six launches back to back.  Results are bit-identical to the calls
+        without prefetch."""
+        _require_gpu(self.main[0].weight, type(self).__name__)
+        if self.__dict__.get("_prefetched"):
+            raise RuntimeError("prefetch_latents: the previous prefetch has not been consumed "
+                               f"({len(self._prefetched)} calls left)")
+        host = []
+        for kind, n in calls:
+            if kind not in ("videos", "images"):
+                raise ValueError(f"prefetch_latents: unknown call kind {kind!r}")
+            select = kind == "images"
+            host.append((select, n, self.video_length) + tuple(self._host_inputs(select, n, self.video_length)))
+        main = torch.cuda.current_stream()
+        lat = self.__dict__.get("_latent_stream")
+        if lat is None or lat.device != main.device:
+            lat = self._latent_stream = torch.cuda.Stream(device=main.device)
+        plans, queue = [], []
+        for select, n, T, x, content, sel in host:      # (plans are created on the caller's stream, like every other plan)
+            plan = self._pool.get((n, T, select), lambda: self._plan_cls(self, n, T, select))
+            plan.busy = True               # reserved: a second call of the same shape gets its own plan and buffers
+            plans.append(plan)
+            queue.append((select, n, T, plan))
+        lat.wait_stream(main)              # weights written on the caller's stream (Adam) are complete
+        with torch.cuda.stream(lat):
+            for plan, (select, n, T, x, content, sel) in zip(plans, host):
+                plan.stage_inputs(x, content, sel)
+            self._launch_latents(plans)
+            ev = torch.cuda.Event()
+            ev.record(lat)
+        for p in plans:
+            p._latent_ev = ev
+        self._prefetched = queue
+
+    def _launch_latents(self, plans):
+        st = stream_ptr()
+        for p in plans:
+            p.fwd_prog.run(st)
+
+    def discard_prefetched(self):
+        """Drop latents that were prefetched but will not be consumed (an exception in the middle of an iteration)."""
+        for _, _, _, plan in self.__dict__.get("_prefetched") or []:
+            plan.busy = False
+        self._prefetched = []
+
+    def _take_prefetched(self, select, n, T):
+        q = self.__dict__.get("_prefetched")
+        if not q:
+            return None
+        s0, n0, T0, plan = q[0]
+        if (s0, n0, T0) != (select, n, T):
+            raise RuntimeError(f"prefetch_latents promised {'sample_images' if s0 else 'sample_videos'}({n0}) next, got "
+                               f"{'sample_images' if select else 'sample_videos'}({n}, video_len={T})")
+        q.pop(0)
+        return plan
 
     # -- reference API ---------------------------------------------------------------------------------------------
     def _host_inputs(self, select, num_samples, T):
@@ -583,8 +658,12 @@ class VideoGenerator(nn.Module):
     def sample_videos(self, num_samples, video_len=None):
         """-> (videos [B, C, T, H, W] fp32, float64 zero labels [B]); models/mocogan.py:271-285."""
         T = video_len if video_len is not None else self.video_length
-        x, content, _ = self._host_inputs(False, num_samples, T)
-        h = self._run(num_samples, T, False, x, content, None)            # [B*T, 1, H, W, C]
+        plan = self._take_prefetched(False, num_samples, T)
+        if plan is not None:
+            h = self._run(num_samples, T, False, None, None, None, plan=plan)
+        else:
+            x, content, _ = self._host_inputs(False, num_samples, T)
+            h = self._run(num_samples, T, False, x, content, None)        # [B*T, 1, H, W, C]
         H, W = h.size(2), h.size(3)
         h = h.view(num_samples, T, H, W, self.n_channels).permute(0, 4, 1, 2, 3)
         return h, self._zero_labels(num_samples, h.device)
@@ -598,8 +677,12 @@ class VideoGenerator(nn.Module):
         the norm is taken over the selected ones, so the accepted step sequence differs (both solutions are within
         rtol 1e-7 of the exact flow; tests/test_gpu_modules.py::test_dopri5_method_against_oracle pins the size)."""
         T = self.video_length
-        x, content, sel = self._host_inputs(True, num_samples, T)
-        h = self._run(num_samples, T, True, x, content, sel)
+        plan = self._take_prefetched(True, num_samples, T)
+        if plan is not None:
+            h = self._run(num_samples, T, True, None, None, None, plan=plan)
+        else:
+            x, content, sel = self._host_inputs(True, num_samples, T)
+            h = self._run(num_samples, T, True, x, content, sel)
         return h.view(num_samples, h.size(2), h.size(3), self.n_channels).permute(0, 3, 1, 2), None
 
     def sample_z_content(self, num_samples, video_len=None):
@@ -716,7 +799,16 @@ class _RnnGenPlan(_GenPlan):
             self.bwd_op.gz = gz.data_ptr()
             self.bwd_op.grads = base.data_ptr()
             self.bwd_op.accumulate = 1 if acc else 0
-            L.run_one(self.bwd_op, stream_ptr())
+            batch = getattr(self.gen, "_adjoint_batch", None)
+            if batch is not None:
+                # the trainer announced how many generator passes this backward holds (video + image path of the G step):
+                # their adjoints -- one workgroup each -- go out as ONE launch once the last decoder backward is through
+                batch["ops"].append(self.bwd_op)
+                batch["keep"].append(gz)
+                if len(batch["ops"]) >= batch["expect"]:
+                    self.gen.flush_adjoints()
+            else:
+                L.run_one(self.bwd_op, stream_ptr())
             self.busy = False
             return None, None
         flat, views, gz = self.stack.backward(gout, need_input_grad=True)
@@ -810,6 +902,27 @@ class VideoGeneratorMNISTODERNN(VideoGeneratorMNIST):
     @staticmethod
     def _take_trajectories(noise, traj):
         return noise[:, traj].contiguous()        # noise stack [T+1, n, 16]: trajectories are the middle axis
+
+    def _launch_latents(self, plans):
+        """All prefetched ODE-RNN solves in one launch (<= 8 per launch), each with its own whole-batch error norm."""
+        st = stream_ptr()
+        for k in range(0, len(plans), 8):
+            chunk = plans[k:k + 8]
+            arr = (L.OdeRnnFwdOp * len(chunk))(*[p.fwd_op for p in chunk])
+            L.call("odernn_fwd_multi", lambda: L.check(L.lib().gode_odernn_fwd_multi(arr, len(chunk), st), "gode_odernn_fwd_multi"))
+
+    def flush_adjoints(self):
+        """Launch the adjoints collected during a backward pass (see _RnnGenPlan.backward)."""
+        batch = getattr(self, "_adjoint_batch", None)
+        if not batch or not batch["ops"]:
+            return
+        ops = batch["ops"]
+        st = stream_ptr()
+        for k in range(0, len(ops), 8):
+            chunk = ops[k:k + 8]
+            arr = (L.OdeRnnBwdOp * len(chunk))(*chunk)
+            L.call("odernn_bwd_multi", lambda: L.check(L.lib().gode_odernn_bwd_multi(arr, len(chunk), st), "gode_odernn_bwd_multi"))
+        batch["ops"], batch["keep"] = [], []
 
     def _draw_motion(self, num_samples, T):
         """h_0 and one e_t per frame, each a fresh FloatTensor(n, d).normal_() on the global torch CPU generator

@@ -456,7 +456,7 @@ class GanTrainer:
 
     def __init__(self, gen, dis_vid, dis_img, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5, d_iters=2,
                  process_group=None, freeze_d_in_g_step=True, freeze_gc=False, direct_grads=True, sync_replicas=True,
-                 overlap_image_d=True, graph=False, pair_d_passes=True):
+                 overlap_image_d=True, graph=False, pair_d_passes=True, prefetch_latents=True):
         self.gen, self.dis_vid, self.dis_img = gen, dis_vid, dis_img
         mk = lambda m: FusedAdam(m.parameters(), lr=lr, betas=betas, weight_decay=weight_decay)  # noqa: E731
         self.gen_opt, self.vid_opt, self.img_opt = mk(gen), mk(dis_vid), mk(dis_img)
@@ -474,6 +474,11 @@ class GanTrainer:
         # pair_d_passes: in the discriminator steps D(real) and D(fake) run as ONE pass over [real; fake] with per-group
         # BatchNorm statistics (forward_pair_joint): same arithmetic per element, half the launches, fuller GEMM grids.
         self.pair_d = bool(pair_d_passes)
+        # prefetch_latents: step() announces the iteration's sample_images / sample_videos calls to the generator up front
+        # (VideoGenerator.prefetch_latents): the host draws are made in the same order, all latent solves go out at once on
+        # a side stream.  Bit-identical results; what it buys is the ODE-RNN generator's six one-workgroup solves per
+        # iteration running side by side in one launch, and the two adjoints of the G step likewise (flush_adjoints).
+        self.prefetch = bool(prefetch_latents)
         self._side = None
         if overlap_image_d and next(dis_img.parameters()).is_cuda:
             self._side = torch.cuda.Stream(device=next(dis_img.parameters()).device)
@@ -632,6 +637,7 @@ class GanTrainer:
                         p.requires_grad_(False)
                         frozen.append(p)
         losses = []
+        batch_adj = self.prefetch and id(self.gen) in self.arenas and hasattr(self.gen, "flush_adjoints")
         try:
             for _ in range(shards):
                 fake_vid, _ = self.gen.sample_videos(B)
@@ -639,9 +645,16 @@ class GanTrainer:
                 pv, _ = self.dis_vid(fake_vid)
                 pi, _ = self.dis_img(fake_img)
                 loss = bce_with_logits_pair(pv, 1.0, pi, 1.0)
+                if batch_adj:      # the video and the image path: two latent adjoints, one launch
+                    self.gen._adjoint_batch = dict(expect=2, ops=[], keep=[])
                 loss.backward(gradient=unit_grad(loss.device))
+                if batch_adj:
+                    self.gen.flush_adjoints()
+                    self.gen._adjoint_batch = None
                 losses.append(loss.detach())
         finally:
+            if batch_adj:
+                self.gen._adjoint_batch = None
             for p in frozen:
                 p.requires_grad_(True)
         self._opt_step(self.gen, self.gen_opt, shards)
@@ -660,11 +673,23 @@ class GanTrainer:
         first = _shards(real_imgs[0])
         B, nsh = first[0].shape[0], len(first)
         li = lv = None
-        for i in range(self.d_iters):
-            li = self.d_image_step(real_imgs[i], _join=False)     # side stream (see overlap_image_d)
-            lv = self.d_video_step(real_vids[i])
-        self._join_side()                                         # the G step reads the updated image discriminator
-        lg = self.g_step(B, nsh)
+        if self.prefetch and hasattr(self.gen, "prefetch_latents") and next(self.gen.parameters()).is_cuda:
+            calls = []
+            for i in range(self.d_iters):
+                calls += [("images", x.shape[0]) for x in _shards(real_imgs[i])]
+                calls += [("videos", x.shape[0]) for x in _shards(real_vids[i])]
+            calls += [("videos", B), ("images", B)] * nsh
+            self.gen.prefetch_latents(calls)
+        try:
+            for i in range(self.d_iters):
+                li = self.d_image_step(real_imgs[i], _join=False)     # side stream (see overlap_image_d)
+                lv = self.d_video_step(real_vids[i])
+            self._join_side()                                         # the G step reads the updated image discriminator
+            lg = self.g_step(B, nsh)
+        except BaseException:
+            if hasattr(self.gen, "discard_prefetched"):
+                self.gen.discard_prefetched()
+            raise
         self._iters += 1
         if self._freeze_gc and self._iters == 2:     # every plan and program exists now
             freeze_host_gc()

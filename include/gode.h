@@ -253,7 +253,7 @@ typedef struct gode_odernn_bwd_op {
   const float* noise; const float* hp; const int32_t* sel_t; const float* gz;
   float* work; float* grads; int32_t N, T, substeps, accumulate, zcols, pad_;
   float rtol, atol;   /* substeps == 0: adaptive adjoint (dopri5 on (y, a, g_theta) per frame, mixed norm), as torchdiffeq */
-  int32_t* sync;      /* as in gode_odernn_fwd_op (adaptive adjoint with N > 32) */
+  int32_t* sync;      /* adaptive adjoint with N > 32: as in the forward op */
   int32_t* nsteps;
 } gode_odernn_bwd_op;
 int gode_odernn_bwd(const gode_odernn_bwd_op* op, void* stream);
