@@ -576,26 +576,32 @@ class VideoGenerator(nn.Module):
         if self.__dict__.get("_prefetched"):
             raise RuntimeError("prefetch_latents: the previous prefetch has not been consumed "
                                f"({len(self._prefetched)} calls left)")
-        host = []
         for kind, n in calls:
             if kind not in ("videos", "images"):
                 raise ValueError(f"prefetch_latents: unknown call kind {kind!r}")
-            select = kind == "images"
-            host.append((select, n, self.video_length) + tuple(self._host_inputs(select, n, self.video_length)))
         main = torch.cuda.current_stream()
         lat = self.__dict__.get("_latent_stream")
         if lat is None or lat.device != main.device:
             lat = self._latent_stream = torch.cuda.Stream(device=main.device)
         plans, queue = [], []
-        for select, n, T, x, content, sel in host:      # (plans are created on the caller's stream, like every other plan)
+        T = self.video_length
+        per_shape = {}
+        for kind, n in calls:
+            per_shape[(kind, n)] = per_shape.get((kind, n), 0) + 1
+        if max(per_shape.values(), default=0) > _Pool.MAX_PLANS:
+            raise RuntimeError(f"prefetch_latents: more than {_Pool.MAX_PLANS} calls of one shape ahead (each holds its own "
+                               "plan and buffers); announce fewer calls at a time")
+        for kind, n in calls:                  # (plans are created on the caller's stream, like every other plan)
+            select = kind == "images"
             plan = self._pool.get((n, T, select), lambda: self._plan_cls(self, n, T, select))
-            plan.busy = True               # reserved: a second call of the same shape gets its own plan and buffers
+            plan.busy = True                   # reserved: a second call of the same shape gets its own plan and buffers
             plans.append(plan)
             queue.append((select, n, T, plan))
-        lat.wait_stream(main)              # weights written on the caller's stream (Adam) are complete
+        lat.wait_stream(main)                  # weights written on the caller's stream (Adam) are complete
         with torch.cuda.stream(lat):
-            for plan, (select, n, T, x, content, sel) in zip(plans, host):
-                plan.stage_inputs(x, content, sel)
+            for plan, (select, n, _, _) in zip(plans, queue):
+                # draw and stage call by call: a generator may hand out a reused host buffer (the ODE-RNN noise stack)
+                plan.stage_inputs(*self._host_inputs(select, n, T))
             self._launch_latents(plans)
             ev = torch.cuda.Event()
             ev.record(lat)

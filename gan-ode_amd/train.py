@@ -673,7 +673,8 @@ class GanTrainer:
         first = _shards(real_imgs[0])
         B, nsh = first[0].shape[0], len(first)
         li = lv = None
-        if self.prefetch and hasattr(self.gen, "prefetch_latents") and next(self.gen.parameters()).is_cuda:
+        # (virtual replicas -- lists of shards, a parity-testing device -- repeat every call per shard: call by call there)
+        if self.prefetch and nsh == 1 and hasattr(self.gen, "prefetch_latents") and next(self.gen.parameters()).is_cuda:
             calls = []
             for i in range(self.d_iters):
                 calls += [("images", x.shape[0]) for x in _shards(real_imgs[i])]

@@ -288,6 +288,44 @@ def test_graph_capture_is_self_contained_with_respect_to_weight_packs(odernn):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("odernn", [False, True])
+def test_prefetched_latents_are_bitwise_the_call_by_call_ones(odernn):
+    """GanTrainer(prefetch_latents=True) (default): every sample_images / sample_videos call of an iteration is announced
+    up front, the host draws are made in the same order and all latent solves go out at once on a side stream (ODE-RNN: one
+    gode_odernn_fwd_multi launch, and the G step's two adjoints one gode_odernn_bwd_multi launch).  Same kernels on the
+    same inputs: losses, weights, BatchNorm buffers and Adam state are bit-identical to the call-by-call schedule."""
+    runs = []
+    for prefetch in (True, False):
+        seed_all(53)
+        gen, dv, di = G.build_mnist(ngf=16, ndf=16)
+        if odernn:
+            gen = G.VideoGeneratorMNISTODERNN(1, 50, 0, 16, 16, ngf=16)
+        gen.cuda(); dv.cuda(); di.cuda()
+        tr = G.GanTrainer(gen, dv, di, prefetch_latents=prefetch)
+        rng = torch.Generator().manual_seed(14)
+        losses = []
+        for it in range(3):
+            imgs = [torch.rand(8, 1, 28, 28, generator=rng).cuda() for _ in range(2)]
+            vids = [torch.rand(8, 16, 1, 28, 28, generator=rng).cuda() for _ in range(2)]
+            seed_all(600 + it)
+            losses.append([float(x) for x in tr.step(imgs, vids)])
+        torch.cuda.synchronize()
+        assert not gen.__dict__.get("_prefetched")
+        state = [t.detach().clone() for m in (gen, dv, di) for t in m.state_dict().values()]
+        state += [tr.gen_opt.state[p]["exp_avg_sq"].clone() for p in gen.parameters() if tr.gen_opt.state.get(p)]
+        runs.append((losses, state))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b)
+    # a call that does not match the announced order is refused, and the queue can be dropped
+    gen.prefetch_latents([("videos", 4), ("images", 4)])
+    with pytest.raises(RuntimeError, match="promised"):
+        gen.sample_images(4)
+    gen.discard_prefetched()
+    with torch.no_grad():
+        assert gen.sample_images(4)[0].shape == (4, 1, 28, 28)
+
+
 def test_second_trainer_on_the_same_networks_does_not_detach_the_first_ones_arenas():
     """Advisor r2: GanTrainer.__init__ binds module._gode_arena; a second trainer on the same networks used to leave the
     first one reducing an arena nobody writes.  Each trainer now re-binds its own arenas at the start of every optimiser
