@@ -36,7 +36,7 @@ class IgemmOp(C.Structure):
 class WgradOp(C.Structure):
     _fields_ = [("g", ConvGeom), ("act", i32), ("xform_on_y", i32), ("splits", i32), ("accumulate", i32),
                 ("x", ptr), ("y", ptr), ("scale", ptr), ("shift", ptr), ("work", ptr), ("dw", ptr),
-                ("co_perm", ptr), ("co_canon", i64), ("xs", i64 * 5), ("ticket", ptr)]
+                ("co_perm", ptr), ("co_canon", i64), ("xs", i64 * 5)]
     KIND = OP_WGRAD
 
 
@@ -126,7 +126,7 @@ _STRUCTS = {0: ConvGeom, OP_IGEMM: IgemmOp, OP_WGRAD: WgradOp, OP_BN_FINALIZE: B
             OP_ODERNN_FWD: OdeRnnFwdOp, OP_ODERNN_BWD: OdeRnnBwdOp, OP_BN_APPLY: BnApplyOp, OP_COL2IM: Col2imOp}
 
 EXPORTS = ["gode_igemm", "gode_igemm_stats_rows", "gode_igemm_stats_rows0", "gode_igemm_work_size", "gode_pack_size", "gode_pack_weights", "gode_wgrad",
-           "gode_wgrad_work_size", "gode_wgrad_ticket_size", "gode_wgrad_auto_splits", "gode_bn_finalize", "gode_bn_bwd",
+           "gode_wgrad_work_size", "gode_wgrad_auto_splits", "gode_bn_finalize", "gode_bn_bwd",
            "gode_bn_bwd_work_size", "gode_bn_apply", "gode_col2im", "gode_ode_fwd", "gode_ode_bwd", "gode_ode_bwd_work_size", "gode_odernn_fwd",
            "gode_odernn_bwd", "gode_odernn_bwd_work_size", "gode_odernn_sync_size", "gode_odernn_fwd_multi",
            "gode_odernn_bwd_multi", "gode_bce_logits",
@@ -164,8 +164,6 @@ def lib():
     L.gode_pack_weights.argtypes = [ptr, C.c_int, ptr, ptr, ptr, i32, ptr]
     L.gode_wgrad_work_size.argtypes = [ptr]
     L.gode_wgrad_work_size.restype = i64
-    L.gode_wgrad_ticket_size.argtypes = [ptr]
-    L.gode_wgrad_ticket_size.restype = i64
     L.gode_wgrad_auto_splits.argtypes = [ptr]
     L.gode_bn_bwd_work_size.argtypes = [i64, i32]
     L.gode_bn_bwd_work_size.restype = i64

@@ -20,10 +20,6 @@ struct WgradArgs {
   int32_t act, xform_on_y;
   int32_t M, chunk, Kt, taps;
   FastDiv dWo, dHo, dDo;
-  // in-kernel split reduction (FAST kernel): the workgroup that finishes a tile's LAST slab adds the tile's `splits` slabs in
-  // slab order and scatters the sums into dw -- no second launch, the slabs are read back while they are still in L2.
-  // ticket[tile] counts arrivals and is reset by the last one (the buffer stays zero between launches).
-  int32_t* ticket; float* dw; const int32_t* co_perm; int32_t splits, accumulate;
 };
 
 template <int WM, int WN, int TM, int TN, bool VECX, bool VECY>
@@ -353,44 +349,6 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_fast_kernel(const WgradArgs
         *reinterpret_cast<bv_t*>(dst + (int64_t)row * a.Kt + col0) = v;
       }
     }
-  if (a.ticket == nullptr) return;
-  // ---- last arriver of this tile: sum its slabs in slab order (fp64 running sum, exactly wgrad_reduce_kernel's arithmetic)
-  __shared__ int s_last;
-  __threadfence();                     // this workgroup's slab stores are visible device-wide before it takes its ticket
-  __syncthreads();
-  if (tid == 0) {
-    int32_t* tk = a.ticket + iblk * gridDim.x + jblk;
-    const int prev = atomicAdd(tk, 1);
-    s_last = prev == a.splits - 1;
-    if (s_last) *tk = 0;               // every other workgroup of the tile has already arrived
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();                     // the other slabs' stores (released before their tickets) are visible
-  const int64_t total = (int64_t)g.Co * a.Kt;
-  constexpr int C4 = BJ / 4;
-  for (int e4 = tid; e4 < BI * C4; e4 += NT) {
-    const int r = e4 / C4, c = (e4 - r * C4) * 4;
-    const int row = iblk * BI + r, col = jblk * BJ + c;
-    if (row >= g.Co || col >= a.Kt) continue;
-    double sd[4] = {0.0, 0.0, 0.0, 0.0};
-    const float* src = a.work + (int64_t)row * a.Kt + col;
-#pragma unroll 4
-    for (int zz = 0; zz < a.splits; ++zz) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)zz * total);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) sd[e] += (double)v[e];
-    }
-    int co = row;
-    if (a.co_perm) { co = a.co_perm[co]; if (co < 0) continue; }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int j = col + e, tap = j / g.Ci, ci = j - tap * g.Ci;
-      float* dptr = a.dw + ((int64_t)co * g.Ci + ci) * a.taps + tap;
-      const float sv = (float)sd[e];
-      *dptr = a.accumulate ? *dptr + sv : sv;
-    }
-  }
 }
 
 // THIN path: very few weight columns (Kt = taps*Ci <= 16: first discriminator layers with 1/3 input channels, the
@@ -810,25 +768,9 @@ extern "C" int64_t gode_wgrad_work_size(const gode_wgrad_op* op) {
   return (int64_t)wg_splits(op) * op->g.Co * taps * op->g.Ci;
 }
 
-// FAST-kernel launches reduce their slabs themselves when the caller supplies a ticket buffer (tiles <= its size)
-static bool wg_fast_path(const gode_wgrad_op* op);
-extern "C" int64_t gode_wgrad_ticket_size(const gode_wgrad_op* op) {
-  if (!op || !wg_fast_path(op)) return 0;
-  const int t = wg_tile(op->g);
-  const int Kt = op->g.kd * op->g.kh * op->g.kw * op->g.Ci;
-  return (int64_t)gode_ceil_div(Kt, wg_bj(t)) * gode_ceil_div(op->g.Co, wg_bi(t));
-}
-
 static bool wg_generic_forced() {
   static const bool f = getenv("GODE_WGRAD_GENERIC") != nullptr;     // read once per process
   return f;
-}
-// geometry-only part of the FAST-path decision (the pointer alignment part is checked at launch)
-static bool wg_fast_path(const gode_wgrad_op* op) {
-  const gode_conv_geom& g = op->g;
-  if (wg_patch(op, nullptr) || (op->splits <= 0 && wg_thin(g))) return false;
-  if (wg_generic_forced() || g.Ci % 4 != 0 || g.Co % 4 != 0) return false;
-  return wg_tile(g) >= 1;             // tile 0 (Co <= 32) keeps the separate reduce: 32-row tiles, hundreds of slabs
 }
 template <int WM, int WN, int TM, int TN>
 static int wg_launch(const WgradArgs& A, bool vx, bool vy, int splits, hipStream_t st) {
@@ -872,15 +814,11 @@ extern "C" int gode_wgrad(const gode_wgrad_op* op, void* stream) {
   A.dWo = make_fastdiv(g.Wo); A.dHo = make_fastdiv(g.Ho); A.dDo = make_fastdiv(g.Do);
   const int splits = wg_splits(op);
   A.chunk = (int)(((M + splits - 1) / splits + 31) / 32 * 32);
-  A.ticket = nullptr; A.dw = op->dw; A.co_perm = op->co_perm; A.splits = splits; A.accumulate = op->accumulate;
   const bool vx = xs[4] == 1 && g.Ci % 4 == 0 && xs[0] % 4 == 0 && xs[1] % 4 == 0 && xs[2] % 4 == 0 && xs[3] % 4 == 0 &&
                   (uintptr_t)op->x % 16 == 0;
   const bool vy = g.Co % 4 == 0 && (uintptr_t)op->y % 16 == 0;
   hipStream_t st = (hipStream_t)stream;
   const int t = wg_tile(g);
-  // in-kernel reduction: FAST kernel, vector operands, 16-byte aligned workspace, a ticket buffer from the caller
-  const bool fused_reduce = op->ticket != nullptr && wg_fast_path(op) && vx && vy && (uintptr_t)op->work % 16 == 0 && A.Kt % 4 == 0;
-  if (fused_reduce) A.ticket = op->ticket;
   WpArgs WP;
   const bool patch = wg_patch(op, &WP);
   if (patch) {
@@ -920,7 +858,6 @@ extern "C" int gode_wgrad(const gode_wgrad_op* op, void* stream) {
   }
   else rc = wg_launch<2, 2, 2, 2>(A, vx, vy, splits, st);
   if (rc) return rc;
-  if (fused_reduce) return 0;
   const int64_t total = (int64_t)g.Co * A.Kt;
   if ((total <= 8192 || (patch && total <= 32768)) && splits >= 16) {   // (patch path: hundreds of slabs of a [Co][Kt] of a few thousand)
     hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((int)((total + RS_OUT - 1) / RS_OUT)), dim3(256), 0, st, op->work, op->dw, g.Co,

@@ -480,13 +480,9 @@ class ConvStack:
                 ops.append(b)
         wg_buf = torch.empty(max(wg_work, 1), **f32)
         bn_buf = torch.empty(max(bn_work, 1), **f32)
-        # arrival counters of the in-kernel split reductions: zero once, every launch leaves them zero (gode.h)
-        tk_n = max([lib.gode_wgrad_ticket_size(C.byref(w)) for _, w, _f in patch["dw"]] + [1])
-        tk_buf = torch.zeros(tk_n, dtype=torch.int32, device=self.device)
-        patch["keep"] = (wg_buf, bn_buf, tk_buf)      # owned by this program (several backward programs coexist)
+        patch["keep"] = (wg_buf, bn_buf)      # owned by this program (several backward programs coexist)
         for _, w, _f in patch["dw"]:
             w.work = wg_buf.data_ptr()
-            w.ticket = tk_buf.data_ptr()
         for b in patch.get("bnb", []):
             if b.mean:
                 b.work = bn_buf.data_ptr()

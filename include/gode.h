@@ -98,15 +98,9 @@ typedef struct gode_wgrad_op {
   float* dw;       /* canonical layout */
   const int32_t* co_perm; int64_t co_canon; /* as in gode_pack_weights, nullable / g.Co */
   int64_t xs[5];   /* element strides of x {N,D,H,W,C}; all zero = channels-last contiguous */
-  /* nullable; >= gode_wgrad_ticket_size(op) int32 words that are ZERO before the first launch (every launch leaves them
-   * zero, so one small buffer serves all ops that run one after the other on a stream): the workgroup that completes a
-   * tile's last slab then adds the tile's slabs in slab order itself -- the same sums as the separate reduction kernel,
-   * one launch less, and the slabs are read back from L2 instead of HBM.  NULL: two launches as before. */
-  int32_t* ticket;
 } gode_wgrad_op;
 int gode_wgrad(const gode_wgrad_op* op, void* stream);
 int64_t gode_wgrad_work_size(const gode_wgrad_op* op);
-int64_t gode_wgrad_ticket_size(const gode_wgrad_op* op);   /* 0: this op's kernel keeps the two-launch form */
 int gode_wgrad_auto_splits(const gode_conv_geom* g);
 
 /* ---- BatchNorm (train mode: batch statistics, eps, momentum as nn.BatchNorm2d/3d defaults) ------------------
