@@ -318,6 +318,15 @@ def _rank_main(a):
     d_ms = _timed(lambda: (tr.d_image_step(imgs[0]), tr.d_video_step(vids[0])), k, wtr, distributed) / k * 1e3
     g_ms = _timed(lambda: tr.g_step(B), k, wtr, distributed) / k * 1e3
     it_ms = _timed(lambda: tr.step(imgs, vids), k, wtr, distributed, after_warmup=G.freeze_host_gc) / k * 1e3
+    # multi-GPU diagnosis: what the five all-reduces of an iteration cost on their own, and what the iteration costs without
+    # them (the replicas' weights drift apart in that leg -- it runs last among the training timings and only its clock is used)
+    coll_ms, it_noar_ms = {}, None
+    if distributed:
+        tr.flush_all()
+        coll_ms = tr.time_collectives()
+        tr.skip_allreduce = True
+        it_noar_ms = _timed(lambda: tr.step(imgs, vids), k, 1, distributed) / k * 1e3
+        tr.skip_allreduce = False
     # the same iteration replayed from a HIP graph (single process only): the host then only draws the noise, uploads
     # it and launches the graph (GanTrainer(graph=True)); bit-identical results (tests/test_gpu_api.py)
     it_graph_ms = None
@@ -376,7 +385,16 @@ def _rank_main(a):
         allreduce = {"collectives_per_iteration": 2 * tr.d_iters + 1 if world > 1 else 0,
                      "bytes_per_iteration_per_rank": (tr.d_iters * (arena_bytes["dis_img"] + arena_bytes["dis_vid"])
                                                       + arena_bytes["gen"]) if world > 1 else 0,
-                     "bucket_bytes": arena_bytes, "backend": (a.backend if distributed else None)}
+                     "bucket_bytes": arena_bytes, "backend": (a.backend if distributed else None),
+                     # each collective timed on its own (same buffers, idle GPU), their sum per iteration, and what the
+                     # iteration pays for them in place (iteration_ms minus the same schedule without collectives): with
+                     # overlap_allreduce the second should stay well below the first
+                     "ms_per_collective": {k_: round(v, 4) for k_, v in coll_ms.items()} if coll_ms else None,
+                     "ms_per_iteration": round(tr.d_iters * (coll_ms.get("dis_img", 0.0) + coll_ms.get("dis_vid", 0.0))
+                                               + coll_ms.get("gen", 0.0), 4) if coll_ms else None,
+                     "iteration_ms_without_allreduce": None if it_noar_ms is None else round(it_noar_ms, 3),
+                     "exposed_ms_per_iteration": None if it_noar_ms is None else round(it_ms - it_noar_ms, 3),
+                     "overlapped": bool(tr.overlap_ar) if world > 1 else None}
         line = {
             "metric": "generated videos/sec (16-frame clips)", "value": round(vps, 2), "unit": "videos/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),

@@ -51,7 +51,7 @@ class BnFinalizeOp(C.Structure):
 class BnBwdOp(C.Structure):
     _fields_ = [("g", ptr), ("y", ptr), ("M", i64), ("C", i32), ("act", i32), ("gamma", ptr), ("mean", ptr),
                 ("invstd", ptr), ("scale", ptr), ("shift", ptr), ("dgamma", ptr), ("dbeta", ptr), ("work", ptr),
-                ("accumulate", i32), ("eval_mode", i32), ("gin", ptr)]
+                ("accumulate", i32), ("eval_mode", i32), ("gin", ptr), ("groups", i32), ("pad2_", i32)]
     KIND = OP_BN_BWD
 
 

@@ -194,6 +194,20 @@ __device__ __forceinline__ float gz_of(float g, float y, float sc, float sh, int
 // partial[blk][2][C] (DOUBLE): sum g_z, sum g_z * xhat   (C % 4 == 0, C/4 <= 256).
 // Both sums cancel heavily (signed gradients), and their error is fed back into every element of g_y, so they are
 // accumulated in fp64 end to end; the kernel stays HBM-bound (2 fp64 FMAs per 8 bytes read).
+// groups == 2 (one discriminator pass over [real; fake], gode_bn_bwd_op.groups): rows [0, M/2) and [M/2, M) are two
+// BatchNorm batches with their own statistics ([2][C] arrays, group-major) -- row chunks never straddle the halves
+// (chunks [0, rows0) belong to group 0), the finalisation forms one coefficient set per group, and both groups' sums go
+// into dgamma / dbeta in group order: the arithmetic of two separate backward passes in one launch triple.
+struct BnbGroups { int groups, rows0, rows; int64_t M0; };
+__device__ __forceinline__ BnbGroups bnb_groups(const gode_bn_bwd_op& a) {
+  BnbGroups G;
+  G.groups = a.groups == 2 ? 2 : 1;
+  G.M0 = G.groups == 2 ? a.M / 2 : a.M;
+  G.rows0 = (int)((G.M0 + BNB_ROWS - 1) / BNB_ROWS);
+  G.rows = G.groups * G.rows0;
+  return G;
+}
+
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const gode_bn_bwd_op a) {
   // block = (row chunk blockIdx.x) x (channel group blockIdx.y); threads = CL float4 channel lanes x RL row lanes
   const int C4 = a.C >> 2, tid = threadIdx.x;
@@ -201,15 +215,18 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const gode_bn_bwd_op
   const int rl = 256 / CL;
   const int cl = tid % CL, rlane = tid / CL;
   const int c4 = blockIdx.y * CL + cl;
+  const BnbGroups G = bnb_groups(a);
+  const int grp = (int)blockIdx.x >= G.rows0 ? 1 : 0;
   __shared__ double red[2][256][4];
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   const bool active = rlane < rl && c4 < C4;
   if (active) {
-    const int c = c4 * 4;
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c), sh = *reinterpret_cast<const f32x4*>(a.shift + c);
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + c), is = *reinterpret_cast<const f32x4*>(a.invstd + c);
-    const int64_t r0 = (int64_t)blockIdx.x * BNB_ROWS;
-    const int64_t r1 = r0 + BNB_ROWS < a.M ? r0 + BNB_ROWS : a.M;
+    const int c = c4 * 4, cs = grp * a.C + c;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + cs), sh = *reinterpret_cast<const f32x4*>(a.shift + cs);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + cs), is = *reinterpret_cast<const f32x4*>(a.invstd + cs);
+    const int64_t r0 = grp * G.M0 + (int64_t)((int)blockIdx.x - grp * G.rows0) * BNB_ROWS;
+    const int64_t rend = grp == 0 ? G.M0 : a.M;
+    const int64_t r1 = r0 + BNB_ROWS < rend ? r0 + BNB_ROWS : rend;
     const float* gsrc = a.gin ? a.gin : a.g;
     for (int64_t r = r0 + rlane; r < r1; r += rl) {
       const f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + r * a.C + c);
@@ -236,49 +253,64 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const gode_bn_bwd_op
   }
 }
 
-// one block per channel: reduce partials, write dgamma/dbeta and the three apply coefficients
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const gode_bn_bwd_op a, int rows) {
+// one block per channel: reduce partials, write dgamma/dbeta and the three apply coefficients (per group)
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const gode_bn_bwd_op a) {
   const int c = blockIdx.x, tid = threadIdx.x;
   __shared__ double red[2][256];
   const double* part = reinterpret_cast<const double*>(a.work);
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = tid; r < rows; r += 256) {
-    s1 += part[(int64_t)r * 2 * a.C + c];
-    s2 += part[(int64_t)r * 2 * a.C + a.C + c];
-  }
-  red[0][tid] = s1; red[1][tid] = s2;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; }
+  const BnbGroups G = bnb_groups(a);
+  float* coef = a.work + (int64_t)G.rows * 4 * a.C;
+  float dbeta_acc = 0.f, dgamma_acc = 0.f;
+  if (tid == 0 && a.accumulate) { dbeta_acc = a.dbeta ? a.dbeta[c] : 0.f; dgamma_acc = a.dgamma ? a.dgamma[c] : 0.f; }
+  for (int grp = 0; grp < G.groups; ++grp) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = grp * G.rows0 + tid; r < (grp + 1) * G.rows0; r += 256) {
+      s1 += part[(int64_t)r * 2 * a.C + c];
+      s2 += part[(int64_t)r * 2 * a.C + a.C + c];
+    }
     __syncthreads();
+    red[0][tid] = s1; red[1][tid] = s2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      dbeta_acc += (float)red[0][0]; dgamma_acc += (float)red[1][0];          // group order: what two passes would add
+      const double Mg = (double)(grp == 0 ? G.M0 : a.M - (G.groups == 2 ? G.M0 : 0));
+      const double invM = 1.0 / Mg;
+      const int cs = grp * a.C + c;
+      const double g = a.gamma ? (double)a.gamma[c] : 1.0, is = (double)a.invstd[cs];
+      const double k = g * is;
+      float* cf = coef + (int64_t)grp * 3 * a.C;
+      // eval mode (running statistics are constants of the forward): g_y = gamma*invstd * g_z, no batch terms
+      cf[c] = (float)k;                                                      // * g_z
+      cf[a.C + c] = a.eval_mode ? 0.f : (float)(k * is * red[1][0] * invM);  // * (mean - y)
+      cf[2 * a.C + c] = a.eval_mode ? 0.f : (float)(k * red[0][0] * invM);   // subtracted constant
+    }
   }
   if (tid == 0) {
-    const float dbeta = (float)red[0][0], dgamma = (float)red[1][0];
-    if (a.dbeta) a.dbeta[c] = a.accumulate ? a.dbeta[c] + dbeta : dbeta;
-    if (a.dgamma) a.dgamma[c] = a.accumulate ? a.dgamma[c] + dgamma : dgamma;
-    const double invM = 1.0 / (double)a.M;
-    const double g = a.gamma ? (double)a.gamma[c] : 1.0, is = (double)a.invstd[c], mu = (double)a.mean[c];
-    const double k = g * is;
-    float* coef = a.work + (int64_t)rows * 4 * a.C;
-    // eval mode (running statistics are constants of the forward): g_y = gamma*invstd * g_z, no batch terms
-    coef[c] = (float)k;                                                      // * g_z
-    coef[a.C + c] = a.eval_mode ? 0.f : (float)(k * is * red[1][0] * invM);  // * (mean - y)
-    coef[2 * a.C + c] = a.eval_mode ? 0.f : (float)(k * red[0][0] * invM);   // subtracted constant
+    if (a.dbeta) a.dbeta[c] = dbeta_acc;
+    if (a.dgamma) a.dgamma[c] = dgamma_acc;
   }
 }
 
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const gode_bn_bwd_op a, int rows) {
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const gode_bn_bwd_op a) {
   const int64_t n4 = a.M * a.C / 4;
-  const float* coef = a.work + (int64_t)rows * 4 * a.C;
+  const BnbGroups G = bnb_groups(a);
+  const float* coef = a.work + (int64_t)G.rows * 4 * a.C;
   const float* gsrc = a.gin ? a.gin : a.g;
+  const int64_t n4_0 = G.M0 * a.C / 4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)((i * 4) % a.C);
+    const int grp = (G.groups == 2 && i >= n4_0) ? 1 : 0;
+    const int c = (int)((i * 4) % a.C), cs = grp * a.C + c;
+    const float* cf = coef + (int64_t)grp * 3 * a.C;
     f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + i * 4);
     const f32x4 y = *reinterpret_cast<const f32x4*>(a.y + i * 4);
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c), sh = *reinterpret_cast<const f32x4*>(a.shift + c);
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + c);
-    const f32x4 cA = *reinterpret_cast<const f32x4*>(coef + c), cB = *reinterpret_cast<const f32x4*>(coef + a.C + c),
-                cC = *reinterpret_cast<const f32x4*>(coef + 2 * a.C + c);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + cs), sh = *reinterpret_cast<const f32x4*>(a.shift + cs);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + cs);
+    const f32x4 cA = *reinterpret_cast<const f32x4*>(cf + c), cB = *reinterpret_cast<const f32x4*>(cf + a.C + c),
+                cC = *reinterpret_cast<const f32x4*>(cf + 2 * a.C + c);
     // g_y = k*g_z - k*dbeta/M - k*invstd*dgamma/M*(y - mean); (mean - y) is formed first so that a large |mean|
     // does not cancel against a separately rounded constant
 #pragma unroll
@@ -294,8 +326,9 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(float* g, const float* gin
 }
 
 extern "C" int64_t gode_bn_bwd_work_size(int64_t M, int32_t C) {
-  const int64_t rows = (M + BNB_ROWS - 1) / BNB_ROWS;
-  return rows * 4 * C + 3 * (int64_t)C;   // fp64 partials (2 floats each) + 3 coefficient vectors
+  // (sized for the two-group form: one more chunk row, two coefficient sets)
+  const int64_t rows = (M + BNB_ROWS - 1) / BNB_ROWS + 1;
+  return rows * 4 * C + 6 * (int64_t)C;   // fp64 partials (2 floats each) + 3 coefficient vectors per group
 }
 
 static int ew_blocks(int64_t n) {
@@ -313,14 +346,17 @@ extern "C" int gode_bn_bwd(const gode_bn_bwd_op* op, void* stream) {
     return 0;
   }
   if (op->C % 4 != 0 || !op->invstd || !op->scale || !op->shift || !op->work) return GODE_E_ARG;
+  if (op->groups == 2 && (op->M % 2 != 0)) return GODE_E_ARG;
   const int C4 = op->C / 4, CL = C4 < BNB_CL ? C4 : BNB_CL;
   if (256 % CL != 0) return GODE_E_SHAPE;
-  const int rows = (int)((op->M + BNB_ROWS - 1) / BNB_ROWS);
+  const int groups = op->groups == 2 ? 2 : 1;
+  const int64_t M0 = groups == 2 ? op->M / 2 : op->M;
+  const int rows = groups * (int)((M0 + BNB_ROWS - 1) / BNB_ROWS);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rows, (C4 + CL - 1) / CL), dim3(256), 0, st, *op);
   GODE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(op->C), dim3(256), 0, st, *op, rows);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(op->C), dim3(256), 0, st, *op);
   GODE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(op->M * op->C / 4)), dim3(256), 0, st, *op, rows);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(op->M * op->C / 4)), dim3(256), 0, st, *op);
   GODE_LAUNCH_CHECK();
   return 0;
 }

@@ -449,28 +449,13 @@ class ConvStack:
             if l > 0:
                 sp, pp = self.specs[l - 1], self.params[l - 1]
                 M, Cc = self._count(l - 1), sp.out_dims()[4]
-                if sp.has_bn and self.groups == 2:
-                    # per-group batch statistics: the reduction and the correction terms run per half of the rows
-                    half = M // 2
-                    for k in range(2):
-                        off = 4 * half * Cc * k
-                        b = L.BnBwdOp(g=self.g[l - 1].data_ptr() + off, y=self.y[l - 1].data_ptr() + off, M=half, C=Cc,
-                                      act=sp.act, gamma=dptr(pp.gamma), mean=self.mean[l - 1].data_ptr() + 4 * Cc * k,
-                                      invstd=self.invstd[l - 1].data_ptr() + 4 * Cc * k,
-                                      scale=self.scale[l - 1].data_ptr() + 4 * Cc * k,
-                                      shift=self.shift[l - 1].data_ptr() + 4 * Cc * k, accumulate=0,
-                                      eval_mode=0 if training else 1)
-                        bn_work = max(bn_work, lib.gode_bn_bwd_work_size(half, Cc))
-                        if need_param_grad:
-                            patch["dgamma"].append((l - 1, b, k == 1))
-                        patch.setdefault("bnb", []).append(b)
-                        ops.append(b)
-                    continue
                 if sp.has_bn:
                     b = L.BnBwdOp(g=dptr(self.g[l - 1]), y=dptr(self.y[l - 1]), M=M, C=Cc, act=sp.act,
                                   gamma=dptr(pp.gamma), mean=dptr(self.mean[l - 1]), invstd=dptr(self.invstd[l - 1]),
                                   scale=dptr(self.scale[l - 1]), shift=dptr(self.shift[l - 1]), accumulate=0,
-                                  eval_mode=0 if training else 1)
+                                  eval_mode=0 if training else 1, groups=2 if self.groups == 2 else 0)
+                    # (groups == 2: per-group batch statistics ([2][C] arrays) in ONE reduce / finalize / apply triple;
+                    # dgamma / dbeta receive both groups' sums in group order)
                     bn_work = max(bn_work, lib.gode_bn_bwd_work_size(M, Cc))
                     if need_param_grad:
                         patch["dgamma"].append((l - 1, b, False))

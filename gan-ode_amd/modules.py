@@ -294,9 +294,19 @@ class _GenPlan:
             into.append((wt, gt, bt, acc))
         return into
 
+    def _decoder_pass_done(self):
+        """The trainer may ask to be told when the LAST decoder backward of a generator step has been queued (the decoder
+        block of the gradient arena is then complete and its all-reduce can start under the latent adjoint)."""
+        cb = getattr(self.gen, "_on_decoder_grads", None)
+        if cb is not None:
+            self.gen._decoder_passes_left -= 1
+            if self.gen._decoder_passes_left == 0:
+                cb()
+
     def backward(self, gout, arena=None):
         if arena is not None:
             _, _, gz = self.stack.backward(gout, need_input_grad=True, into=self._decoder_into(arena))
+            self._decoder_pass_done()
             ode = [q for q in self._ode_params() if q is not None]
             tgt = [arena.target(q) for q in ode]
             base, acc = tgt[0]
@@ -800,6 +810,7 @@ class _RnnGenPlan(_GenPlan):
             # decoder gradients and the 2176 ODEFunc + GRU gradients go straight into the trainer's arena: the eight
             # tensors are its tail, contiguous in the kernel's output order (VideoGeneratorMNISTODERNN._arena_tail)
             _, _, gz = self.stack.backward(gout, need_input_grad=True, into=self._decoder_into(arena))
+            self._decoder_pass_done()
             tgt = [arena.target(q) for q in self._rnn_params()]
             base, acc = tgt[0]
             self.bwd_op.gz = gz.data_ptr()

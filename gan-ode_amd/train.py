@@ -456,7 +456,7 @@ class GanTrainer:
 
     def __init__(self, gen, dis_vid, dis_img, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5, d_iters=2,
                  process_group=None, freeze_d_in_g_step=True, freeze_gc=False, direct_grads=True, sync_replicas=True,
-                 overlap_image_d=True, graph=False, pair_d_passes=True, prefetch_latents=True):
+                 overlap_image_d=True, graph=False, pair_d_passes=True, prefetch_latents=True, overlap_allreduce=True):
         self.gen, self.dis_vid, self.dis_img = gen, dis_vid, dis_img
         mk = lambda m: FusedAdam(m.parameters(), lr=lr, betas=betas, weight_decay=weight_decay)  # noqa: E731
         self.gen_opt, self.vid_opt, self.img_opt = mk(gen), mk(dis_vid), mk(dis_img)
@@ -479,6 +479,15 @@ class GanTrainer:
         # a side stream.  Bit-identical results; what it buys is the ODE-RNN generator's six one-workgroup solves per
         # iteration running side by side in one launch, and the two adjoints of the G step likewise (flush_adjoints).
         self.prefetch = bool(prefetch_latents)
+        # overlap_allreduce (world > 1): every all-reduce is issued asynchronously (the process group's own stream) and the
+        # optimiser step that consumes it is DEFERRED to the point where that network is next needed -- a discriminator's
+        # all-reduce then runs under the next no-grad generator forward, and the generator's arena goes out in two parts:
+        # the decoder's 13 MB as soon as the last decoder backward kernel is queued (under the latent adjoint), the
+        # ODEFunc / GRU tail after the adjoint.  Same kernels in the same per-stream order: bit-identical to the serial form.
+        self.overlap_ar = bool(overlap_allreduce)
+        self._pending = {}            # id(model) -> (opt, works, gscale, feed)
+        self._early = {}              # id(model) -> (work, floats): the part of an arena whose all-reduce is already out
+        self.skip_allreduce = False   # measurement only (bench.py): run the schedule without collectives
         self._side = None
         if overlap_image_d and next(dis_img.parameters()).is_cuda:
             self._side = torch.cuda.Stream(device=next(dis_img.parameters()).device)
@@ -520,7 +529,60 @@ class GanTrainer:
             if hasattr(m, "invalidate_packs"):
                 m.invalidate_packs()
 
+    # -- collectives ---------------------------------------------------------------------------------------------------
+    def _all_reduce(self, flat, async_op):
+        """One sum over the replicas of a flat fp32 gradient buffer (RCCL over xGMI; gloo in the rehearsals)."""
+        if self.skip_allreduce:
+            return None
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def _flush(self, model):
+        """The deferred optimiser step of `model`, if one is pending: wait for its all-reduce(s), then Adam."""
+        ent = self._pending.pop(id(model), None)
+        if ent is None:
+            return
+        opt, works, gscale, feed = ent
+        for w in works:
+            if w is not None:
+                w.wait()              # (the current stream waits; the host does not block with RCCL)
+        opt.step(gscale=gscale, feed=feed)
+
+    def _early_decoder_allreduce(self):
+        a = self.arenas[id(self.gen)]
+        tail = sum(p.numel() for p in (self.gen._arena_tail() if hasattr(self.gen, "_arena_tail") else []))
+        head = a.flat.numel() - tail
+        self._early[id(self.gen)] = (self._all_reduce(a.flat[:head], True), head)
+
+    def flush_all(self):
+        for m in (self.dis_img, self.dis_vid, self.gen):
+            self._flush(m)
+
+    def time_collectives(self, reps=10):
+        """Milliseconds of each of the iteration's all-reduces on its own (same buffers, nothing else running): what the
+        fabric charges for them; compare with the iteration time of a run with skip_allreduce to see what is exposed."""
+        out = {}
+        if self.world <= 1:
+            return out
+        for name, m in (("dis_img", self.dis_img), ("dis_vid", self.dis_vid), ("gen", self.gen)):
+            a = self.arenas.get(id(m))
+            if a is None:
+                continue
+            buf = torch.zeros_like(a.flat)
+            for _ in range(2):
+                dist.all_reduce(buf, group=self.group)
+            torch.cuda.synchronize()
+            dist.barrier(group=self.group)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                dist.all_reduce(buf, group=self.group)
+            e1.record()
+            torch.cuda.synchronize()
+            out[name] = e0.elapsed_time(e1) / reps
+        return out
+
     def _begin(self, model, opt):
+        self._flush(model)            # the previous step's deferred update reads this arena
         a = self.arenas.get(id(model))
         if a is not None:
             # (re)bind: the autograd nodes look the arena up on the module, and a second trainer built on the same
@@ -538,10 +600,21 @@ class GanTrainer:
                 raise RuntimeError("another GanTrainer re-bound this network's gradient arena in the middle of an optimiser "
                                    "step: the backward kernels wrote into its arena, not this one")
             a.end()
-            if self.world > 1:       # the arena is the bucket: one collective, no packing copies
-                dist.all_reduce(a.flat, op=dist.ReduceOp.SUM, group=self.group)
             feed = getattr(opt, "_feed", None)
-            opt.step(gscale=gscale, feed=feed if (feed is not None and feed.recording) else None)
+            feed = feed if (feed is not None and feed.recording) else None
+            if self.world > 1 and self.overlap_ar and feed is None:
+                # the arena is the bucket: no packing copies.  Parts that went out early (the generator's decoder block,
+                # see g_step) are skipped here; the optimiser step waits in _flush, where the network is next needed
+                early = self._early.pop(id(model), None)
+                if early is None:
+                    works = [self._all_reduce(a.flat, True)]
+                else:
+                    works = [early[0], self._all_reduce(a.flat[early[1]:], True)]
+                self._pending[id(model)] = (opt, works, gscale, None)
+                return
+            if self.world > 1:       # serial form: one collective, then the update
+                self._all_reduce(a.flat, False)
+            opt.step(gscale=gscale, feed=feed)
             return
         if self.world > 1:
             b = self.buckets[id(model)]
@@ -605,15 +678,23 @@ class GanTrainer:
     def d_video_step(self, real_vid):
         """mnist_moco_ode.py:133-150.  real_vid: [B,T,C,H,W], or a list of such shards."""
         shards = _shards(real_vid)
-        self._begin(self.dis_vid, self.vid_opt)
         losses = []
+        begun = False
         for x in shards:
             B = x.shape[0]
             real = x.transpose(1, 2)                            # [B,T,C,H,W] -> [B,C,T,H,W] view, read in place
+            if not self.pair_d and not begun:
+                self._begin(self.dis_vid, self.vid_opt)
+                begun = True
             if not self.pair_d:
                 pr, _ = self.dis_vid(real)
             with torch.no_grad():
                 fake, _ = self.gen.sample_videos(B)
+            if not begun:
+                # (paired pass) the generator forward above does not read this discriminator: its previous step's
+                # all-reduce -- deferred, see overlap_allreduce -- has been running under it; now wait, update, begin
+                self._begin(self.dis_vid, self.vid_opt)
+                begun = True
             if self.pair_d:
                 loss = bce_with_logits_halves(self.dis_vid.forward_pair_joint(real, fake), 1.0, 0.0)
             else:
@@ -638,6 +719,7 @@ class GanTrainer:
                         frozen.append(p)
         losses = []
         batch_adj = self.prefetch and id(self.gen) in self.arenas and hasattr(self.gen, "flush_adjoints")
+        early_ar = self.world > 1 and self.overlap_ar and id(self.gen) in self.arenas
         try:
             for _ in range(shards):
                 fake_vid, _ = self.gen.sample_videos(B)
@@ -647,7 +729,13 @@ class GanTrainer:
                 loss = bce_with_logits_pair(pv, 1.0, pi, 1.0)
                 if batch_adj:      # the video and the image path: two latent adjoints, one launch
                     self.gen._adjoint_batch = dict(expect=2, ops=[], keep=[])
+                if early_ar and shards == 1:
+                    # both generator passes' decoder backward queued -> the decoder block of the arena is complete: its
+                    # all-reduce goes out now, under the latent adjoint(s)
+                    self.gen._decoder_passes_left = 2
+                    self.gen._on_decoder_grads = self._early_decoder_allreduce
                 loss.backward(gradient=unit_grad(loss.device))
+                self.gen._on_decoder_grads = None
                 if batch_adj:
                     self.gen.flush_adjoints()
                     self.gen._adjoint_batch = None
@@ -685,8 +773,18 @@ class GanTrainer:
             for i in range(self.d_iters):
                 li = self.d_image_step(real_imgs[i], _join=False)     # side stream (see overlap_image_d)
                 lv = self.d_video_step(real_vids[i])
+            if self._pending:
+                # the G step reads both discriminators: their deferred updates land now (the image discriminator's on its
+                # side stream, where its step ran)
+                if self._side is not None:
+                    with torch.cuda.stream(self._side):
+                        self._flush(self.dis_img)
+                else:
+                    self._flush(self.dis_img)
+                self._flush(self.dis_vid)
             self._join_side()                                         # the G step reads the updated image discriminator
             lg = self.g_step(B, nsh)
+            self._flush(self.gen)          # weights are current when step() returns (checkpoints, the next prefetch)
         except BaseException:
             if hasattr(self.gen, "discard_prefetched"):
                 self.gen.discard_prefetched()

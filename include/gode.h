@@ -155,6 +155,10 @@ typedef struct gode_bn_bwd_op {
   float* dgamma; float* dbeta; float* work; int32_t accumulate, eval_mode;
   const float* gin; /* nullable: read g_a from here instead of g (g is then write-only); lets the caller's upstream
                        gradient tensor be consumed in place without being modified */
+  /* groups == 2 (M even): rows [0, M/2) and [M/2, M) are two BatchNorm batches of one grouped pass -- mean / invstd /
+   * scale / shift are [2][C] (group-major, as gode_bn_finalize writes them), the batch terms use each group's own sums,
+   * dgamma / dbeta receive both groups' sums in group order (what the reference's two backward passes add up to). */
+  int32_t groups, pad2_;
 } gode_bn_bwd_op;
 int gode_bn_bwd(const gode_bn_bwd_op* op, void* stream);
 int64_t gode_bn_bwd_work_size(int64_t M, int32_t C);

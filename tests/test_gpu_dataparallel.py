@@ -112,7 +112,31 @@ def test_two_rank_processes_on_one_gpu_through_the_bench_launcher():
     ar = rec["allreduce"]
     assert ar["collectives_per_iteration"] == 5
     assert ar["bytes_per_iteration_per_rank"] == 2 * (ar["bucket_bytes"]["dis_img"] + ar["bucket_bytes"]["dis_vid"]) + ar["bucket_bytes"]["gen"]
+    # the diagnosis fields of the first real multi-GPU run: every collective timed on its own, their sum per iteration, and
+    # the iteration with / without them
+    assert set(ar["ms_per_collective"]) == {"dis_img", "dis_vid", "gen"} and all(v > 0 for v in ar["ms_per_collective"].values())
+    assert ar["ms_per_iteration"] > 0 and ar["iteration_ms_without_allreduce"] > 0 and ar["overlapped"] is True
+    assert isinstance(ar["exposed_ms_per_iteration"], float)
     assert rec["cpu_baseline"] is None          # rank-0-at-N=1 only
+
+
+@pytest.mark.parametrize("which", ["ode", "odernn"])
+def test_overlapped_allreduce_schedule_is_bitwise_the_serial_one(which):
+    """GanTrainer(overlap_allreduce=True) (default): asynchronous all-reduces, the optimiser step deferred to where the
+    network is next needed, the generator's arena in two parts (decoder block under the latent adjoint, ODE tail after
+    it) -- against the serial form (collective, then Adam) on two rank processes sharing the GPU over gloo: same losses,
+    same weights and Adam moments, bit for bit; replicas equal among themselves."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_gode_launch", os.path.join(REPO, "gan-ode_amd", "launch.py"))
+    launch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(launch)
+    recs = []
+    for mode in ("overlap", "serial"):
+        code, out = launch.spawn_ranks(2, [sys.executable, os.path.join(REPO, "tests", "_dp_rank.py"), mode, which], timeout=600)
+        assert code == 0, out[-3000:]
+        recs.append(json.loads([ln for ln in out.splitlines() if ln.startswith('{"mode"')][0]))
+    assert recs[0]["losses"] == recs[1]["losses"], recs
+    assert recs[0]["digest"] == recs[1]["digest"]
 
 
 def test_single_gpu_bench_line_through_the_spawn_path():

@@ -243,6 +243,54 @@ def test_bn_finalize_and_backward(M, Cc):
     assert rel_err((yd * d["scale"] + d["shift"]).cpu(), ref.detach()) < TOL
 
 
+@pytest.mark.parametrize("M,Cc", [(2 * 700, 64), (2 * 257, 8), (2 * 4096, 256)])
+def test_bn_backward_two_groups_in_one_launch_triple_is_bitwise_two_passes(M, Cc):
+    """gode_bn_bwd_op.groups == 2 (the paired discriminator pass): rows [0, M/2) and [M/2, M) with their own batch
+    statistics in ONE reduce / finalize / apply triple against two single-group ops on the halves (the second adding to
+    dgamma / dbeta): bit-identical gradients."""
+    gen = torch.Generator().manual_seed(M + Cc)
+    y = torch.randn(M, Cc, generator=gen) * 2 + 1
+    ga = torch.randn(M, Cc, generator=gen)
+    gam = (torch.rand(Cc, generator=gen) + 0.5).cuda()
+    h = M // 2
+    st = {}
+    for k in ("mean", "invstd", "scale", "shift"):
+        st[k] = torch.empty(2, Cc, device="cuda")
+    for grp in range(2):
+        yy = y[grp * h:(grp + 1) * h].double()
+        mean, var = yy.mean(0), yy.var(0, unbiased=False)
+        inv = 1.0 / torch.sqrt(var + 1e-5)
+        st["mean"][grp] = mean.float().cuda(); st["invstd"][grp] = inv.float().cuda()
+        st["scale"][grp] = (gam.cpu().double() * inv).float().cuda()
+        st["shift"][grp] = (0.3 - mean * gam.cpu().double() * inv).float().cuda()
+    lib = L.lib()
+    yd = y.cuda()
+    work = torch.empty(lib.gode_bn_bwd_work_size(M, Cc), device="cuda")
+    base = torch.randn(2, Cc, generator=gen).cuda()
+    outs = []
+    for mode in ("grouped", "two"):
+        g = ga.clone().cuda()
+        dg, db = base[0].clone(), base[1].clone()
+        if mode == "grouped":
+            op = L.BnBwdOp(g=g.data_ptr(), y=yd.data_ptr(), M=M, C=Cc, act=L.ACT_LRELU, gamma=gam.data_ptr(),
+                           mean=st["mean"].data_ptr(), invstd=st["invstd"].data_ptr(), scale=st["scale"].data_ptr(),
+                           shift=st["shift"].data_ptr(), dgamma=dg.data_ptr(), dbeta=db.data_ptr(), work=work.data_ptr(),
+                           accumulate=1, groups=2)
+            L.run_one(op, stream())
+        else:
+            for grp in range(2):
+                off = 4 * h * Cc * grp
+                op = L.BnBwdOp(g=g.data_ptr() + off, y=yd.data_ptr() + off, M=h, C=Cc, act=L.ACT_LRELU, gamma=gam.data_ptr(),
+                               mean=st["mean"][grp].data_ptr(), invstd=st["invstd"][grp].data_ptr(),
+                               scale=st["scale"][grp].data_ptr(), shift=st["shift"][grp].data_ptr(), dgamma=dg.data_ptr(),
+                               dbeta=db.data_ptr(), work=work.data_ptr(), accumulate=1)
+                L.run_one(op, stream())
+        torch.cuda.synchronize()
+        outs.append((g.clone(), dg.clone(), db.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def _ode_setup(N, T, seed, prenet=True):
     from oracle.mocogan_ref import OdeRhs
     torch.manual_seed(seed)
