@@ -30,9 +30,11 @@
 #include "ode_common.h"
 #include "valu_common.h"
 
-#define RV_TRAJ 32
-#define RV_THREADS 512
-#define RV_WAVES 8
+#ifndef RV_WAVES
+#define RV_WAVES 8                   // (scripts/exp/odernn_waves.sh builds 4 to measure one wave per SIMD)
+#endif
+#define RV_TRAJ (4 * RV_WAVES)
+#define RV_THREADS (64 * RV_WAVES)
 #define RV_MAX_JOBS 8
 #define RV_MAX_WGS (GODE_ODERNN_SYNC_MAX_N / RV_TRAJ)
 #define RV_MAX_TRIALS 20000          // per frame; torchdiffeq's max_num_steps is 2^31 - 1
@@ -235,6 +237,10 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_fwd_valu_kernel(const RnnFw
   int par = 0;
   if (threadIdx.x == 0) R.dead = 0;
 
+#ifdef GODE_ODE_STAMPS
+  const long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+  long long acc_stage = 0, acc_mv = 0, acc_sum = 0, acc_ctl = 0, last_end = 0, acc_trials = 0, st_loop = 0;
+#endif
   float h = valid ? a.noise[(int64_t)n * 16 + i] : 0.f;
   stage_rnn_params(a.p, P, true);
   if (a.content) rnn_broadcast_content(a.content, a.z, a.sel_t, a.N, T, a.zcols, n0);      // stores only
@@ -256,7 +262,16 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_fwd_valu_kernel(const RnnFw
   const int tsel = (a.sel_t && valid) ? a.sel_t[n] : -1;
   if (valid && a.hs) a.hs[((int64_t)n * (T + 1)) * 16 + i] = h;
 
+#ifdef GODE_ODE_STAMPS
+  st_loop = __builtin_amdgcn_s_memtime();
+#endif
   for (int t = 0; t < T; ++t) {
+#ifdef GODE_ODE_STAMPS
+    last_end = 0;
+#endif
+    // (this frame's GRU input is requested now: a dependent ~2 us HBM round trip that would otherwise sit between the
+    // solve and the GRU on every frame -- 25 % of the launch in the stamped build)
+    const float e = valid ? a.noise[((int64_t)(t + 1) * a.N + n) * 16 + i] : 0.f;
     // ---- h' = y(1), y' = f(y), y(0) = h.  The clock and the step size are fp64, as torchdiffeq keeps them.
     float y0 = h;
     float u0 = mv16(w1, y0, b1);
@@ -283,6 +298,9 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_fwd_valu_kernel(const RnnFw
     bool stalled = false;
     for (;;) {
       if (R.dead || steps >= RV_MAX_TRIALS || !(tcur + dtd > tcur)) { stalled = true; break; }
+#ifdef GODE_ODE_STAMPS
+      const long long sA = __builtin_amdgcn_s_memtime();
+#endif
       const float dt = (float)dtd;
       const float h2 = fast_tanh(fmaf(dt * A21, q1, u0));
       const float q2 = mv16(Mw, h2, cq);
@@ -296,6 +314,10 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_fwd_valu_kernel(const RnnFw
       const float q6 = mv16(Mw, h6, cq);
       const float u7 = fmaf(dt, B1 * q1 + B3 * q3 + B4 * q4 + B5 * q5 + B6 * q6, u0);
       const float h7 = fast_tanh(u7);
+#ifdef GODE_ODE_STAMPS
+      asm volatile("" ::"v"(h7));
+      const long long sB = __builtin_amdgcn_s_memtime();
+#endif
       const float Hb = B1 * h1 + B3 * h3 + B4 * h4 + B5 * h5 + B6 * h6;
       const float He = E1 * h1 + E3 * h3 + E4 * h4 + E5 * h5 + E6 * h6 + E7 * h7;
       const float y1 = fmaf(dt, mv16(w2, Hb, b2), y0);
@@ -304,9 +326,21 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_fwd_valu_kernel(const RnnFw
       const float rr = err / tol;
       float v[1] = {valid ? rr * rr : 0.f};
       const float q7 = mv16(Mw, h7, cq);            // next step's q1 if this one is accepted: issued under the sum's latency
+#ifdef GODE_ODE_STAMPS
+      asm volatile("" ::"v"(q7), "v"(v[0]));
+      const long long sC = __builtin_amdgcn_s_memtime();
+#endif
       batch_sum<1>(v, &R, par, X);
       const float ratio = sqrtf(v[0] * inv_count);
       ++steps;
+#ifdef GODE_ODE_STAMPS
+      {
+        const long long sD = __builtin_amdgcn_s_memtime();
+        acc_stage += sB - sA; acc_mv += sC - sB; acc_sum += sD - sC; acc_trials += 1;
+        if (last_end) acc_ctl += sA - last_end;
+        last_end = sD;
+      }
+#endif
       if (ratio <= 1.f) {
         if (tcur + dtd >= 1.0) {   // dense output at t = 1 (4th-order interpolant through the mid-point)
           const float x = (float)((1.0 - tcur) / dtd);
@@ -325,7 +359,6 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_fwd_valu_kernel(const RnnFw
     if (stalled) return;              // uniform over the workgroup (and, through the shared norm, over the call)
     if (valid && a.hp) a.hp[((int64_t)n * T + t) * 16 + i] = yend;
     // ---- GRUCell(e_t, h')
-    const float e = valid ? a.noise[((int64_t)(t + 1) * a.N + n) * 16 + i] : 0.f;
     const float r = fast_sigmoid(mv16(wih[0], e, bih[0]) + mv16(whh[0], yend, bhh[0]));
     const float zg = fast_sigmoid(mv16(wih[1], e, bih[1]) + mv16(whh[1], yend, bhh[1]));
     const float nn = fast_tanh(mv16(wih[2], e, bih[2]) + r * mv16(whh[2], yend, bhh[2]));
@@ -336,6 +369,15 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_fwd_valu_kernel(const RnnFw
       else if (t == tsel) a.z[(int64_t)n * a.zcols + i] = h;
     }
   }
+#ifdef GODE_ODE_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long st1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+    printf("odernn_fwd_valu: %lld cycles in %.1f us -> %.0f MHz; set-up %lld; %lld trial steps: 6 stages %lld | y1, err, q7 mat-vecs %lld | "
+           "batch sum %lld | controller %lld; rest of the frames (initial step, dense output, GRU, stores) %lld\n",
+           st1 - st0, (double)(rt1 - rt0) / 100.0, (double)(st1 - st0) / ((double)(rt1 - rt0) / 100.0), st_loop - st0, acc_trials,
+           acc_stage, acc_mv, acc_sum, acc_ctl, (st1 - st_loop) - acc_stage - acc_mv - acc_sum - acc_ctl);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -747,15 +789,24 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_bwd_valu_kernel(const RnnBw
   float gth[2] = {0.f, 0.f};           // this thread's two elements of the ODEFunc gradient (batch total over all frames)
   const int tsel = (a.sel_t && valid) ? a.sel_t[n] : -1;
   float carry = 0.f;
+  // the three per-frame inputs (upstream gradient, GRU input, post-ODE state) are requested one frame ahead: dependent
+  // HBM round trips otherwise, ~2 us per frame on the critical path
+  auto load_up = [&](int t) -> float {
+    if (!valid || t < 0) return 0.f;
+    if (a.sel_t == nullptr) return a.gz[((int64_t)n * T + t) * a.zcols + i];
+    return t == tsel ? a.gz[(int64_t)n * a.zcols + i] : 0.f;
+  };
+  float up_n = load_up(T - 1);
+  float e_n = valid ? a.noise[((int64_t)T * a.N + n) * 16 + i] : 0.f;
+  float hp_n = valid ? a.hp[((int64_t)n * T + (T - 1)) * 16 + i] : 0.f;
   for (int t = T - 1; t >= 0; --t) {
-    float up = 0.f;
-    if (valid) {
-      if (a.sel_t == nullptr) up = a.gz[((int64_t)n * T + t) * a.zcols + i];
-      else if (t == tsel) up = a.gz[(int64_t)n * a.zcols + i];
+    const float up = up_n, e = e_n, hp = hp_n;
+    if (t > 0) {
+      up_n = load_up(t - 1);
+      e_n = valid ? a.noise[((int64_t)t * a.N + n) * 16 + i] : 0.f;
+      hp_n = valid ? a.hp[((int64_t)n * T + (t - 1)) * 16 + i] : 0.f;
     }
     const float gh = carry + up;                                                  // dL/dh_{t+1}
-    const float e = valid ? a.noise[((int64_t)(t + 1) * a.N + n) * 16 + i] : 0.f;
-    const float hp = valid ? a.hp[((int64_t)n * T + t) * 16 + i] : 0.f;
     float adj;
     {   // GRU recompute + backward; the weight arrangement is gathered from LDS per frame (it would not fit the register file
         // next to the solver's four matrices)

@@ -59,12 +59,15 @@ def multi(kind, ds):
     return lambda: L.check(fn(arr, len(ds), st()))
 
 
-for N in (32, 64, 1024):
+only = [int(v) for v in sys.argv[1:]]
+for N in (only or (32, 64, 1024)):
     d = make(N)
     us = timed(lambda: L.run_one(d["fop"], st()))
     print(f"forward N={N:5d}: {us:8.1f} us   trial steps/frame {d['nst'].cpu().tolist()}")
     us = timed(lambda: L.run_one(d["bop"], st()), reps=5)
     print(f"adjoint N={N:5d}: {us:8.1f} us   trial steps/frame {d['nstb'].cpu().tolist()}")
+if only:
+    sys.exit(0)
 ds = [make(32) for _ in range(6)]
 print(f"forward 6 x N=32 in one launch: {timed(multi('f', ds)):8.1f} us")
 print(f"adjoint 2 x N=32 in one launch: {timed(multi('b', ds[:2]), reps=5):8.1f} us")
