@@ -71,7 +71,7 @@ class OdeBwdOp(C.Structure):
     _fields_ = [("p", OdeParams), ("x", ptr), ("traj", ptr), ("dt", ptr), ("sel_t", ptr), ("gz", ptr),
                 ("work", ptr), ("grads", ptr), ("N", i32), ("T", i32), ("substeps", i32), ("prenet", i32),
                 ("accumulate", i32), ("zcols", i32), ("bstep_off", ptr), ("bstep_dt", ptr), ("method", i32),
-                ("pad_", i32), ("rtol", f32), ("atol", f32), ("tout", ptr)]
+                ("pad_", i32), ("rtol", f32), ("atol", f32), ("tout", ptr), ("nsteps", ptr)]
     KIND = OP_ODE_BWD
 
 

@@ -142,7 +142,9 @@ struct AdjSolver {
   // One adjoint call segment: integrate (y, a, G) from tau0 to tau1 (tau = -t increasing), return a and this wave's G
   // at tau1 read off the 4th-order interpolant of the last accepted step (RKAdaptiveStepsizeODESolver flow).
   // y is not returned: the caller resets it to the stored forward state, as odeint_adjoint does.  steps: trial count.
-  __device__ void solve(f32x4 y0, f32x4& a0, Th& G, double tau0, double tau1, int& steps) {
+  // Returns false when the call stalled (trial-step limit, or a step size that no longer advances the fp64 clock:
+  // torchdiffeq asserts there); the state is then only partially integrated and the caller reports a negative count.
+  __device__ bool solve(f32x4 y0, f32x4& a0, Th& G, double tau0, double tau1, int& steps) {
     f32x4 k1y, k1a;
     Th X1;
     eval(y0, a0, k1y, k1a, X1, true);
@@ -161,7 +163,9 @@ struct AdjSolver {
       dtd = (double)fminf(100.f * h0, h1);
     }
     double tcur = tau0;
-    for (; steps < 1000000;) {
+    const int step_limit = steps + 100000;
+    for (;;) {
+      if (steps >= step_limit || !(tcur + dtd > tcur)) return false;
       const float dt = (float)dtd;
       f32x4 k2y, k2a, k3y, k3a, k4y, k4a, k5y, k5a, k6y, k6a, k7y, k7a;
       Th X, S = th_zero(), E = th_zero(), M = th_zero(), X7;
@@ -229,7 +233,7 @@ struct AdjSolver {
         __syncthreads();
         for (int e = threadIdx.x; e < TH_N; e += blockDim.x) L->gtot[e] += img_total(0, e);
         __syncthreads();
-        if (last) return;
+        if (last) return true;
         tcur += dtd; y0 = y1; k1y = k7y; k1a = k7a; X1 = X7;
       }
       float fac;
@@ -252,7 +256,7 @@ struct AdjSolver {
 
 // ODE-RNN backward with the adaptive adjoint: per frame GRU backward, then ONE adjoint call over [1, 0] (its theta state
 // starts at zero, as each odeint_adjoint call's does).  One partial row of `work` per wave (16 trajectories).
-__global__ void __launch_bounds__(ADJ_BLOCK * 4) odernn_bwd_adaptive_kernel(const gode_odernn_bwd_op a, int* nsteps) {
+__global__ void __launch_bounds__(ADJ_BLOCK * 4) odernn_bwd_adaptive_kernel(const gode_odernn_bwd_op a) {
   __shared__ AdjLds lds;
   AdjSolver S;
   const int l = threadIdx.x & 63;
@@ -331,11 +335,13 @@ __global__ void __launch_bounds__(ADJ_BLOCK * 4) odernn_bwd_adaptive_kernel(cons
     for (int k = threadIdx.x; k < TH_N; k += blockDim.x) lds.gtot[k] = 0.f;
     __syncthreads();
     Th G = th_zero();
-    S.solve(hp, adj, G, -1.0, 0.0, steps);
+    const int before = steps;
+    const bool ok = S.solve(hp, adj, G, -1.0, 0.0, steps);
+    if (a.nsteps && blockIdx.x == 0 && threadIdx.x == 0) a.nsteps[t] = ok ? steps - before : -(steps - before) - 1;
+    if (!ok) break;                  // (uniform over the workgroup: the decision comes from the joint norm)
     th_axpy(Gacc, 1.f, G);
     carry = adj;                                                                 // dL/dh_t
   }
-  if (nsteps && threadIdx.x == 0) nsteps[blockIdx.x] = steps;
   if (blockIdx.x * ADJ_BLOCK + S.wv * 16 >= a.N) return;      // a wave without trajectories owns no partial row
   const f32x4 sb1 = sum_over_samples(Gacc.b1), sb2 = sum_over_samples(Gacc.b2);
 #pragma unroll
@@ -362,7 +368,7 @@ int gode_launch_odernn_bwd_adaptive(const gode_odernn_bwd_op* op, hipStream_t st
   const int nblocks = (op->N + ADJ_BLOCK - 1) / ADJ_BLOCK;
   // every wave writes one partial row; rows of waves beyond N hold zeros (their lanes are masked)
   const int per = op->N < ADJ_BLOCK ? op->N : ADJ_BLOCK;
-  hipLaunchKernelGGL(odernn_bwd_adaptive_kernel, dim3(nblocks), dim3(((per + 15) / 16) * 64), 0, st, *op, (int*)nullptr);
+  hipLaunchKernelGGL(odernn_bwd_adaptive_kernel, dim3(nblocks), dim3(((per + 15) / 16) * 64), 0, st, *op);
   GODE_LAUNCH_CHECK();
   return 0;
 }
@@ -411,11 +417,13 @@ __global__ void __launch_bounds__(ADJ_BLOCK * 4) ode_dopri5_bwd_kernel(const god
   Th G = th_zero();
   f32x4 adj = upstream(T - 1);
   int steps = 0;
-  for (int i = T - 1; i >= 1; --i) {
+  bool ok = true;
+  for (int i = T - 1; i >= 1 && ok; --i) {
     const f32x4 y = valid ? ld4(a.traj + ((int64_t)n * T + i) * 16 + 4 * g) : zero4();
-    S.solve(y, adj, G, -(double)a.tout[i], -(double)a.tout[i - 1], steps);
+    ok = S.solve(y, adj, G, -(double)a.tout[i], -(double)a.tout[i - 1], steps);
     adj = adj + upstream(i - 1);
   }
+  if (a.nsteps && threadIdx.x == 0) a.nsteps[blockIdx.x] = ok ? steps : -steps - 1;
   const bool wave_live = blockIdx.x * ADJ_BLOCK + S.wv * 16 < a.N;      // a wave without trajectories owns no partial row
   if (wave_live) {
     const f32x4 sb1 = sum_over_samples(G.b1), sb2 = sum_over_samples(G.b2);

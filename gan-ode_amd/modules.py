@@ -226,6 +226,8 @@ class _GenPlan:
                 self.fwd_op.tout, self.fwd_op.nsteps = dptr(self._tout), dptr(self._nsteps)
                 self.bwd_op.method, self.bwd_op.rtol, self.bwd_op.atol = 1, float(self.gen.ode_rtol), float(self.gen.ode_atol)
                 self.bwd_op.tout = dptr(self._tout)
+                self._nsteps_bwd = torch.zeros((self.n + 63) // 64, dtype=torch.int32, device=self.device)
+                self.bwd_op.nsteps = dptr(self._nsteps_bwd)
             elif self.gen.ode_method != "rk4":
                 raise NotImplementedError(f"ode_method {self.gen.ode_method!r}: libgode implements 'rk4' (the reference's "
                                           "call) and 'dopri5'")

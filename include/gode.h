@@ -210,6 +210,8 @@ typedef struct gode_ode_bwd_op {
    * the theta state is carried across the output intervals, the solver restarts on each.  method 1 with substeps > 0:
    * the same adjoint discretised with `substeps` fixed Kutta-3/8 steps per interval (round-1 behaviour; dt required). */
   int32_t method, pad_; float rtol, atol; const float* tout;
+  int32_t* nsteps;   /* nullable, adaptive adjoint only: [ceil(N/64)] trial steps of the adjoint call per workgroup; a negative
+                        entry reports a call that stalled (trial-step limit / step-size underflow: torchdiffeq asserts there) */
 } gode_ode_bwd_op;
 int gode_ode_bwd(const gode_ode_bwd_op* op, void* stream);
 int64_t gode_ode_bwd_work_size(int32_t N);

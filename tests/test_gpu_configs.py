@@ -234,6 +234,7 @@ def test_config3_ucf_batch16_dopri5_full_width():
     assert abs(float(loss.detach()) - float(rl.detach())) / abs(float(rl.detach())) < TOL
     plan = gen._pool.plans[(B, 16, False)][0]
     assert 3 <= int(plan._nsteps[0]) < 200
+    assert 15 <= int(plan._nsteps_bwd[0]) < 2000      # the adaptive adjoint's trial steps (a stalled call reports a negative count)
     ref = dict(ogen.named_parameters())
     for k in ("ode_fn.fn.0.weight", "ode_fn.fn.2.weight", "linear.0.weight", "linear.2.weight"):
         # max-norm error against the fp32 oracle: both sides carry the 1e-3-level fp32 noise of the 64x64 decoder +
