@@ -76,7 +76,53 @@ def _pmc_traffic(layer):
     return None, None
 
 
-def _kernel_roofline(gen, reps=30):
+def _live_pmc_traffic(layer_index, timeout_s=150):
+    """HBM-side (L2-miss / fabric) bytes per launch of decoder layer `layer_index`, measured NOW: two child runs of
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --roofline-only` (separate passes, as
+    MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled for gfx950's 64-B tally of 128-B requests; counter unit KB), last of
+    the 30 timed launches of that layer.  Children, not this process: counters cannot be collected from inside.  Returns
+    (bytes, description) or (None, reason)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    env["TMPDIR"] = "/tmp"
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="gode_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "t", "--",
+                                sys.executable, os.path.abspath(__file__), "--roofline-only"], cwd="/tmp", env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited {r.returncode}"
+            path = None
+            for root, _, files in os.walk(d):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        path = os.path.join(root, f)
+            if path is None:
+                return None, "no counter_collection.csv"
+            rows = [q for q in csv.DictReader(open(path)) if q["Counter_Name"] == counter and "igemm_fast" in q["Kernel_Name"]]
+            rows.sort(key=lambda q: int(q["Dispatch_Id"]))
+            # --roofline-only: one sample_videos call (layers 0..3 once each), then 3 warm-up + 30 timed launches per layer
+            if len(rows) != 4 + 4 * 33:
+                return None, f"unexpected dispatch count {len(rows)}"
+            vals[counter] = float(rows[4 + layer_index * 33 + 32]["Counter_Value"])
+        except Exception as e:      # noqa: BLE001 -- a measurement aid: any failure falls back to the committed file
+            return None, f"{type(e).__name__}: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024), \
+        "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes of `bench.py --roofline-only` in this run"
+
+
+def _kernel_roofline(gen, reps=30, live_traffic=False):
     """Times each decoder GEMM launch on its own with HIP events on the launch stream and returns the roofline
     object of the launch class that dominates the forward pass."""
     import gan_ode_amd._lib as L
@@ -106,7 +152,15 @@ def _kernel_roofline(gen, reps=30):
         flop = 2.0 * macs * rows
         per_layer.append(dict(layer=name, ms=ms, gflop=flop / 1e9, tflops=flop / ms / 1e9))
     dom = max(per_layer[1:4], key=lambda d: d["ms"])
-    traffic, traffic_src = _pmc_traffic(dom["layer"])
+    traffic, traffic_src = (None, None)
+    if live_traffic:
+        traffic, traffic_src = _live_pmc_traffic(per_layer.index(dom))
+        if traffic is None:
+            live_fail = traffic_src
+            traffic, traffic_src = _pmc_traffic(dom["layer"])
+            traffic_src = f"{traffic_src} (live collection failed: {live_fail})"
+    else:
+        traffic, traffic_src = _pmc_traffic(dom["layer"])
     roof = {"bound": "mfma", "kernel": "igemm_fast_kernel (fp32 MFMA 32x32x2), " + dom["layer"],
             "achieved": round(dom["tflops"], 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(dom["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -199,6 +253,9 @@ def _parse():
     ap.add_argument("--train-steps", type=int, default=10, help="iterations for the G/D step timings")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="skip the HIP-graph replay timing of the training iteration")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="take roofline.traffic from the newest committed PMC file instead of measuring it in two rocprofv3 "
+                         "child passes (~20 s each)")
     ap.add_argument("--spawn", action="store_true",
                     help="go through the rank launcher even for --gpus 1 (N > 1 always does unless a launcher already "
                          "set WORLD_SIZE)")
@@ -362,7 +419,7 @@ def _rank_main(a):
     if distributed:
         dist.barrier()       # every rank leaves the collective phase before rank 0 goes off to its single-rank legs
     if rank == 0:
-        roof = _kernel_roofline(gen) if a.config == "mnist" else None
+        roof = _kernel_roofline(gen, live_traffic=not a.no_live_traffic) if a.config == "mnist" else None
         it_roof = _iteration_roofline(tr, imgs, vids, min(it_ms, it_graph_ms) if it_graph_ms else it_ms) if not distributed else None
         cpu = None if a.no_cpu_baseline or distributed or a.config != "mnist" else _cpu_baseline(threads=G.host_cpu_quota())
         workload = {"mnist": "Rotated-MNIST MoCoGAN+ODE, gen.sample_videos(32): batch 32/GPU, 16x1x28x28, ngf=ndf=64, "

@@ -145,7 +145,7 @@ def test_single_gpu_bench_line_through_the_spawn_path():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--spawn", "--steps", "5", "--warmup", "2",
-                        "--train-steps", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+                        "--train-steps", "2", "--no-cpu-baseline", "--no-live-traffic"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][0])
     assert rec["n_gpus"] == 1 and rec["roofline"]["bound"] == "mfma" and rec["iteration"]["algorithmic_gflop"] > 100
