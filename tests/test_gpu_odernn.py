@@ -23,7 +23,9 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-@pytest.mark.parametrize("N,T", [(20, 5), (32, 16), (300, 3)])
+# (33, 2): a second workgroup holding ONE trajectory; (4096, 2): the co-residency cap of the whole-batch norm exchange (128
+# workgroups waiting for each other); (4128, 2): one workgroup more -- the MFMA fallback with one norm per 64 trajectories
+@pytest.mark.parametrize("N,T", [(20, 5), (32, 16), (300, 3), (33, 2), (4096, 2), (4128, 2)])
 def test_odernn_kernels_against_oracle(N, T):
     torch.manual_seed(N)
     f = M.OdeRhs(16, 16)
@@ -69,7 +71,8 @@ def test_odernn_kernels_against_oracle(N, T):
     # (an accept / reject decision within rounding of ratio = 1 may fall either way in two fp32 evaluations -- at rtol 1e-7 the
     # error estimate is a few ulps of the state: measured, one frame of the N = 20 case takes 6 trial steps where the oracle takes 7)
     diff = [abs(a - b) for a, b in zip(steps.tolist(), ref_trials)]
-    assert max(diff) <= 1 and sum(1 for d in diff if d) <= max(1, T // 8), (steps.tolist(), ref_trials)
+    if N <= 4096:        # (above: the fallback's norm is per 64-trajectory workgroup, its step sequence its own)
+        assert max(diff) <= 1 and sum(1 for d in diff if d) <= max(1, T // 8), (steps.tolist(), ref_trials)
     gz = torch.zeros(N * T, 72, device="cuda")
     gz.view(N, T, 72)[:, :, :16] = gup.cuda()
     grads = torch.full((L.ODERNN_NPARAM,), float("nan"), device="cuda")
