@@ -177,7 +177,7 @@ def _op_class_and_flop(op):
     adjoint recomputes the stages and adds the two vector-Jacobian products (3x)."""
     import gan_ode_amd._lib as L
     if isinstance(op, str):
-        return ("ode" if op.startswith("odernn") else op), 0.0
+        return ("ode" if op.startswith("ode") else op), 0.0
     k = op.KIND
     if k in (L.OP_IGEMM, L.OP_WGRAD):
         g = op.g

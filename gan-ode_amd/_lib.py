@@ -63,7 +63,7 @@ class OdeFwdOp(C.Structure):
     _fields_ = [("p", OdeParams), ("x", ptr), ("content", ptr), ("dt", ptr), ("sel_t", ptr), ("z", ptr),
                 ("traj", ptr), ("N", i32), ("T", i32), ("substeps", i32), ("prenet", i32), ("zcols", i32), ("G", i32),
                 ("grid_dt", ptr), ("emit_at", ptr), ("emit_w", ptr), ("method", i32), ("pad2_", i32), ("rtol", f32),
-                ("atol", f32), ("tout", ptr), ("nsteps", ptr)]
+                ("atol", f32), ("tout", ptr), ("nsteps", ptr), ("sync", ptr)]
     KIND = OP_ODE_FWD
 
 
@@ -71,7 +71,7 @@ class OdeBwdOp(C.Structure):
     _fields_ = [("p", OdeParams), ("x", ptr), ("traj", ptr), ("dt", ptr), ("sel_t", ptr), ("gz", ptr),
                 ("work", ptr), ("grads", ptr), ("N", i32), ("T", i32), ("substeps", i32), ("prenet", i32),
                 ("accumulate", i32), ("zcols", i32), ("bstep_off", ptr), ("bstep_dt", ptr), ("method", i32),
-                ("pad_", i32), ("rtol", f32), ("atol", f32), ("tout", ptr), ("nsteps", ptr)]
+                ("pad_", i32), ("rtol", f32), ("atol", f32), ("tout", ptr), ("nsteps", ptr), ("sync", ptr)]
     KIND = OP_ODE_BWD
 
 
@@ -127,7 +127,7 @@ _STRUCTS = {0: ConvGeom, OP_IGEMM: IgemmOp, OP_WGRAD: WgradOp, OP_BN_FINALIZE: B
 
 EXPORTS = ["gode_igemm", "gode_igemm_stats_rows", "gode_igemm_stats_rows0", "gode_igemm_work_size", "gode_pack_size", "gode_pack_weights", "gode_wgrad",
            "gode_wgrad_work_size", "gode_wgrad_auto_splits", "gode_bn_finalize", "gode_bn_bwd",
-           "gode_bn_bwd_work_size", "gode_bn_apply", "gode_col2im", "gode_ode_fwd", "gode_ode_bwd", "gode_ode_bwd_work_size", "gode_odernn_fwd",
+           "gode_bn_bwd_work_size", "gode_bn_apply", "gode_col2im", "gode_ode_fwd", "gode_ode_bwd", "gode_ode_fwd_multi", "gode_ode_bwd_multi", "gode_ode_bwd_work_size", "gode_odernn_fwd",
            "gode_odernn_bwd", "gode_odernn_bwd_work_size", "gode_odernn_sync_size", "gode_odernn_fwd_multi",
            "gode_odernn_bwd_multi", "gode_bce_logits",
            "gode_adam_l2", "gode_adam_multi", "gode_adam_multi_dev", "gode_scale", "gode_run", "gode_version", "gode_sizeof"]
@@ -173,6 +173,8 @@ def lib():
     L.gode_odernn_bwd_work_size.restype = i64
     L.gode_odernn_sync_size.argtypes = [i32]
     L.gode_odernn_sync_size.restype = i64
+    L.gode_ode_fwd_multi.argtypes = [ptr, i32, ptr]
+    L.gode_ode_bwd_multi.argtypes = [ptr, i32, ptr]
     L.gode_odernn_fwd_multi.argtypes = [ptr, i32, ptr]
     L.gode_odernn_bwd_multi.argtypes = [ptr, i32, ptr]
     L.gode_scale.argtypes = [ptr, ptr, i64, f32, C.c_int, ptr]

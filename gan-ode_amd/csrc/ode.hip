@@ -123,7 +123,7 @@ extern "C" int gode_ode_fwd(const gode_ode_fwd_op* op, void* stream) {
     if (op->zcols < 68 || op->zcols % 4 != 0) return GODE_E_ARG;
     if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2) return GODE_E_ARG;
     if (op->prenet && (!op->p.Wa || !op->p.ba || !op->p.Wb || !op->p.bb)) return GODE_E_ARG;
-    return gode_launch_ode_dopri5(op, (hipStream_t)stream);
+    return gode_ode_fwd_multi(op, 1, stream);       // odernn_valu.hip (VALU kernels; MFMA fallback inside)
   }
   if (op && op->method != 0) return GODE_E_ARG;
   if (!op || !op->x || !op->z || !op->dt || op->N <= 0 || op->T < 1 || op->substeps < 1) return GODE_E_ARG;
@@ -294,6 +294,16 @@ extern "C" int64_t gode_ode_bwd_work_size(int32_t N) { return (int64_t)((N + 15)
 
 int gode_launch_ode_dopri5_bwd(const gode_ode_bwd_op* op, hipStream_t st);   // adj_adaptive.hip
 
+static int ode_bwd_reduce(const gode_ode_bwd_op* op, int nblk, hipStream_t st);
+
+// the round-2 adaptive adjoint (adj_adaptive.hip, norm per 64-trajectory workgroup) with its reduction: the fallback of
+// gode_ode_bwd_multi above the co-residency limit
+int gode_launch_ode_dopri5_bwd_mfma(const gode_ode_bwd_op* op, hipStream_t st) {
+  const int rc = gode_launch_ode_dopri5_bwd(op, st);
+  if (rc) return rc;
+  return ode_bwd_reduce(op, (op->N + 15) / 16, st);
+}
+
 extern "C" int gode_ode_bwd(const gode_ode_bwd_op* op, void* stream) {
   const bool adaptive = op && op->method == 1 && op->substeps == 0;
   if (!op || !op->traj || !op->gz || !op->work || !op->grads || op->N <= 0 || op->T < 1) return GODE_E_ARG;
@@ -305,16 +315,18 @@ extern "C" int gode_ode_bwd(const gode_ode_bwd_op* op, void* stream) {
   if ((op->bstep_off == nullptr) != (op->bstep_dt == nullptr)) return GODE_E_ARG;
   const int nblk = (op->N + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
-  if (adaptive) {
-    const int rc = gode_launch_ode_dopri5_bwd(op, st);
-    if (rc) return rc;
-  } else if (!ode_use_mfma(op->N)) {
+  if (adaptive) return gode_ode_bwd_multi(op, 1, stream);      // odernn_valu.hip (reduces into grads itself)
+  if (!ode_use_mfma(op->N)) {
     const int rc = gode_launch_ode_bwd_valu(op, st);
     if (rc) return rc;
   } else {
     hipLaunchKernelGGL(ode_bwd_kernel, dim3(nblk), dim3(64), 0, st, *op);
     GODE_LAUNCH_CHECK();
   }
+  return ode_bwd_reduce(op, nblk, st);
+}
+
+static int ode_bwd_reduce(const gode_ode_bwd_op* op, int nblk, hipStream_t st) {
   const int first = op->prenet ? 0 : OFF_W1;
   const int gx = (GODE_ODE_NPARAM - first + 255) / 256;
   int stride = 1;

@@ -521,15 +521,16 @@ struct AdjV {
   }
   // torchdiffeq's mixed norm of an augmented vector: its y / a parts per lane (vy, va, already divided by their scale), its
   // theta part as the per-wave images in LDS -- mode 0: slot 0 = V, scale = atol + rtol |G|;  mode 1: slot 0 = E, slot 1 = S,
-  // scale = atol + rtol max(|G|, |G + S|);  mode -1: no theta part (the state itself at the start of a call: G = 0).
-  // The batch totals of S stay in st[] for the accepted-state update.
+  // scale = atol + rtol max(|G|, |G + S|);  mode -1: no theta part (the state itself at the start of a call: G = 0);
+  // mode 2: the accepted theta state G itself (a later output interval of the same adjoint call: G carried over), whose
+  // batch total every thread already owns -- no images.  The batch totals of S stay in st[] for the accepted-state update.
   __device__ __forceinline__ float mixed(float vy, float va, int mode) {
     float v[6];
     v[0] = valid ? vy * vy : 0.f;
     v[1] = valid ? va * va : 0.f;
     v[2] = v[3] = v[4] = v[5] = 0.f;
     float V[2] = {0.f, 0.f}, S[2] = {0.f, 0.f};
-    if (mode >= 0) {
+    if (mode == 0 || mode == 1) {
       __syncthreads();                     // the images written by put_image are complete
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -584,8 +585,8 @@ struct AdjV {
         const int e = (int)threadIdx.x + RV_THREADS * k;
         if (e < TH_N) {
           const float G = gt[k];
-          const float sc = mode == 0 ? atol + rtol * fabsf(G) : atol + rtol * fmaxf(fabsf(G), fabsf(G + S[k]));
-          const float q = V[k] / sc;
+          const float sc = mode == 1 ? atol + rtol * fmaxf(fabsf(G), fabsf(G + S[k])) : atol + rtol * fabsf(G);
+          const float q = (mode == 2 ? G : V[k]) / sc;
           const int comp = e < TH_B1 ? 0 : (e < TH_W2 ? 1 : (e < TH_B2 ? 2 : 3));
           v[2 + comp] += q * q;
         }
@@ -648,18 +649,20 @@ struct AdjV {
     __syncthreads();                       // the images may be rewritten
   }
 
-  // One adjoint call: integrate (y, a, G) from tau = -1 to tau = 0 (tau = -t increasing), G(-1) = 0.  On return a0 holds a
-  // at tau = 0 (4th-order interpolant of the last accepted step) and gt[] this thread's two elements of the BATCH total of
-  // G(0) (the per-wave shares never leave the trial step that produced them).  steps: trial count of the call (returned
-  // negative when the call stalled).
-  __device__ void solve(float y0, float& a0, int& steps) {
-    gt[0] = gt[1] = 0.f;
+  // One adjoint solve: integrate (y, a, G) from tau0 to tau1 (tau = -t increasing).  On return a0 holds a at tau1 (4th-order
+  // interpolant of the last accepted step) and gt[] this thread's two elements of the BATCH total of G(tau1) (the
+  // per-wave shares never leave the trial step that produced them).  steps: running trial count (returned negative when the
+  // solve stalled).
+  // tau0 -> tau1: the interval in reversed time; fresh: the theta state starts at zero (a new adjoint call), else it is carried
+  // over from the previous output interval of the same call (gt[] holds its batch total) and the solver restarts.
+  __device__ void solve(float y0, float& a0, double tau0, double tau1, int& steps, bool fresh) {
+    if (fresh) gt[0] = gt[1] = 0.f;
     float k1y, k1a, h1, du1;
     eval(y0, a0, k1y, k1a, h1, du1);
     double dtd;
-    {   // _select_initial_step (order 4) under the mixed norm; the theta state is zero at the start of a call
+    {   // _select_initial_step (order 4) under the mixed norm
       const float scy = atol + fabsf(y0) * rtol, sca = atol + fabsf(a0) * rtol;
-      const float d0 = mixed(y0 / scy, a0 / sca, -1);
+      const float d0 = mixed(y0 / scy, a0 / sca, fresh ? -1 : 2);
       Acc4 X1; acc_zero(X1);
       theta_acc(X1, 1.f, a0, h1, du1, y0);
       put_image(0, X1, 1.f);
@@ -676,9 +679,10 @@ struct AdjV {
       const float hh = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : fast_pow(0.01f / fmaxf(d1, d2), 0.2f);
       dtd = (double)fminf(100.f * h0, hh);
     }
-    double tcur = -1.0;
+    double tcur = tau0;
+    const int step_limit = steps + RV_MAX_TRIALS;
     for (;;) {
-      if (R->dead || steps >= RV_MAX_TRIALS || !(tcur + dtd > tcur)) { steps = -steps - 1; return; }
+      if (R->dead || steps >= step_limit || !(tcur + dtd > tcur)) { steps = -steps - 1; return; }
       const float dt = (float)dtd;
       Acc4 S, E, M;
       acc_zero(S); acc_zero(E); acc_zero(M);
@@ -711,11 +715,11 @@ struct AdjV {
       const float ratio = mixed(erry / toly, erra / tola, 1);
       ++steps;
       if (ratio <= 1.f) {
-        if (tcur + dtd >= 0.0) {
-          // last step: the value at tau = 0 off the 4th-order interpolant through (z0, z_mid, z1, f0, f1); the abscissa is
+        if (tcur + dtd >= tau1) {
+          // last step: the value at tau1 off the 4th-order interpolant through (z0, z_mid, z1, f0, f1); the abscissa is
           // formed from the fp32-rounded times, as torchdiffeq does.  z(x) = z0 + wS (z1 - z0) + wM (z_mid - z0)
           // + dt (w1 f0 + w7 f1); for the (linear) theta components the same weights apply to S, M, X1, X7.
-          const float x = (0.f - (float)tcur) / ((float)(tcur + dtd) - (float)tcur);
+          const float x = ((float)tau1 - (float)tcur) / ((float)(tcur + dtd) - (float)tcur);
           float wS, wM, w1c, w7c;
           interp_weights(x, wS, wM, w1c, w7c);
           const float dmid = C1 * k1a + C3 * k3a + C4 * k4a + C5 * k5a + C6 * k6a + C7 * k7a;
@@ -854,7 +858,7 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_bwd_valu_kernel(const RnnBw
     }
     // adjoint call of this frame's solve: state (y = h', a = adj, g_theta = 0) at t = 1 back to t = 0
     int steps = 0;
-    S.solve(hp, adj, steps);
+    S.solve(hp, adj, -1.0, 0.0, steps, true);
     if (a.nsteps && wg == 0 && threadIdx.x == 0) a.nsteps[t] = steps;
     if (steps < 0) break;                // stalled: uniform over the call
     gth[0] += S.gt[0]; gth[1] += S.gt[1];
@@ -963,3 +967,391 @@ extern "C" int gode_odernn_bwd_multi(const gode_odernn_bwd_op* ops, int32_t coun
 }
 
 extern "C" int gode_odernn_bwd(const gode_odernn_bwd_op* op, void* stream) { return gode_odernn_bwd_multi(op, 1, stream); }
+
+// =================================================================================================================
+// ode_method = "dopri5" on the plain Neural-ODE generators (gode_ode_fwd_op / gode_ode_bwd_op with method == 1; what
+// BASELINE configs[3] words for UCF -- the reference's own call is rk4): pre-net, then ONE adaptive solve over the T output
+// times, every output read off the 4th-order interpolant of the accepted step that covers it (RKAdaptiveStepsizeODESolver:
+// advance while target > t1, then evaluate); the adjoint is ONE call over the T - 1 intervals with the theta state
+// carried and the solver restarted per interval (oracle/ode_ref.py:_Adjoint.backward).  Same mapping, fused algebra,
+// whole-batch norm and multi-solve launches as the ODE-RNN kernels above; the round-2 MFMA kernels (odernn.hip,
+// adj_adaptive.hip) remain above GODE_ODERNN_SYNC_MAX_N trajectories per launch.
+// =================================================================================================================
+#define DP_WA 0
+#define DP_BA 1024
+#define DP_WB 1088
+#define DP_BB 2112
+#define DP_W1 2128
+#define DP_B1 2384
+#define DP_W2 2400
+#define DP_B2 2656
+#define DP_M GODE_ODE_NPARAM
+#define DP_C (GODE_ODE_NPARAM + 256)
+#define DP_N (GODE_ODE_NPARAM + 272)
+
+__device__ __forceinline__ void stage_ode_params(const gode_ode_params& p, int prenet, float* P) {
+  const int t = threadIdx.x;
+  if (prenet) {
+    for (int k = t; k < 1024; k += RV_THREADS) { P[DP_WA + k] = p.Wa[k]; P[DP_WB + k] = p.Wb[k]; }
+    if (t < 64) P[DP_BA + t] = p.ba[t];
+    if (t < 16) P[DP_BB + t] = p.bb[t];
+  }
+  for (int k = t; k < 256; k += RV_THREADS) { P[DP_W1 + k] = p.W1[k]; P[DP_W2 + k] = p.W2[k]; }
+  if (t < 16) { P[DP_B1 + t] = p.b1[t]; P[DP_B2 + t] = p.b2[t]; }
+  __syncthreads();
+}
+
+struct OdeFwdJobs { gode_ode_fwd_op op[RV_MAX_JOBS]; int32_t nblk[RV_MAX_JOBS]; int32_t count; };
+
+__global__ void __launch_bounds__(RV_THREADS) ode_dopri5_fwd_valu_kernel(const OdeFwdJobs J) {
+  __shared__ float P[DP_N];
+  __shared__ RedLds R;
+  int job = 0, wg = blockIdx.x;
+  while (job + 1 < J.count && wg >= J.nblk[job]) { wg -= J.nblk[job]; ++job; }
+  const gode_ode_fwd_op a = J.op[job];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, tl = lane >> 4;
+  const int n0 = wg * RV_TRAJ, n = n0 + wave * 4 + tl;
+  const bool valid = n < a.N;
+  const int T = a.T;
+  const float inv_count = 1.f / ((float)a.N * 16.f);
+  const float rtol = a.rtol, atol = a.atol;
+  XSync X;
+  X.nwg = J.nblk[job]; X.wg = wg; X.seq = 0;
+  X.counter = a.sync; X.slots = a.sync ? reinterpret_cast<float*>(a.sync) + XS_HDR : nullptr;
+  int par = 0;
+  if (threadIdx.x == 0) R.dead = 0;
+
+  float y0 = valid ? a.x[(int64_t)n * 16 + i] : 0.f;
+  stage_ode_params(a.p, a.prenet, P);
+  if (threadIdx.x < 256) {           // M = W1 W2, c = W1 b2 (fp64 accumulation)
+    const int r = threadIdx.x >> 4, j = threadIdx.x & 15;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += (double)P[DP_W1 + r * 16 + k] * (double)P[DP_W2 + k * 16 + j];
+    P[DP_M + threadIdx.x] = (float)s;
+  } else if (threadIdx.x < 272) {
+    const int r = threadIdx.x - 256;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += (double)P[DP_W1 + r * 16 + k] * (double)P[DP_B2 + k];
+    P[DP_C + r] = (float)s;
+  }
+  __syncthreads();
+  if (a.content) rnn_broadcast_content(a.content, a.z, a.sel_t, a.N, T, a.zcols, n0);      // stores only
+
+  int src[16];
+  probe_sources(i, src);
+  if (a.prenet) {
+    // Linear(16,64) -> LReLU -> Linear(64,16) -> LReLU: the 64 hidden units as four row-resident chunks
+    float acc = P[DP_BB + i];
+#pragma unroll 1
+    for (int m = 0; m < 4; ++m) {
+      W16 wa, wb;
+      load_rows(wa, P + DP_WA, 16, 16 * m, 0, i, src);
+      load_rows(wb, P + DP_WB, 64, 0, 16 * m, i, src);
+      const float hh = lrelu1(mv16(wa, y0, P[DP_BA + 16 * m + i]));
+      acc = mv16(wb, hh, acc);
+    }
+    y0 = lrelu1(acc);
+  }
+  W16 Mw, w1, w2;
+  load_rows(Mw, P + DP_M, 16, 0, 0, i, src);
+  load_rows(w1, P + DP_W1, 16, 0, 0, i, src);
+  load_rows(w2, P + DP_W2, 16, 0, 0, i, src);
+  const float b1 = P[DP_B1 + i], b2 = P[DP_B2 + i], cq = P[DP_C + i];
+  const int tsel = (a.sel_t && valid) ? a.sel_t[n] : -1;
+  auto emit = [&](int t, float v) {
+    if (!valid) return;
+    if (a.traj) a.traj[((int64_t)n * T + t) * 16 + i] = v;
+    if (a.sel_t == nullptr) a.z[((int64_t)n * T + t) * a.zcols + i] = v;
+    else if (t == tsel) a.z[(int64_t)n * a.zcols + i] = v;
+  };
+  emit(0, y0);
+
+  float u0 = mv16(w1, y0, b1);
+  float h1 = fast_tanh(u0);
+  float q1 = mv16(Mw, h1, cq);
+  double dtd;
+  {   // torchdiffeq _select_initial_step (order 4)
+    const float f0 = mv16(w2, h1, b2);
+    const float sc = atol + fabsf(y0) * rtol;
+    float v[2] = {valid ? (y0 / sc) * (y0 / sc) : 0.f, valid ? (f0 / sc) * (f0 / sc) : 0.f};
+    batch_sum<2>(v, &R, par, X);
+    const float d0 = sqrtf(v[0] * inv_count), d1 = sqrtf(v[1] * inv_count);
+    const float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
+    const float df = mv16(w2, fast_tanh(fmaf(h0, q1, u0)) - h1, 0.f);
+    float w[1] = {valid ? (df / sc) * (df / sc) : 0.f};
+    batch_sum<1>(w, &R, par, X);
+    const float d2 = sqrtf(w[0] * inv_count) / h0;
+    const float hh = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : fast_pow(0.01f / fmaxf(d1, d2), 0.2f);
+    dtd = (double)fminf(100.f * h0, hh);
+  }
+  double tcur = (double)a.tout[0], seg0 = tcur, seg1 = tcur;
+  // the interpolant of the last accepted step, in the linear-in-h form: y(x) = sy + sdt (W2 (wS sHb + wM sHm + w1 sh1 + w7 sh7) + b2 (...))
+  float sy = y0, sdt = 0.f, sHb = 0.f, sHm = 0.f, sh1 = 0.f, sh7 = 0.f;
+  int steps = 0;
+  bool stalled = false;
+  for (int j = 1; j < T && !stalled; ++j) {
+    const double target = (double)a.tout[j];
+    while (target > seg1) {
+      if (R.dead || steps >= RV_MAX_TRIALS || !(tcur + dtd > tcur)) { stalled = true; break; }
+      const float dt = (float)dtd;
+      const float h2 = fast_tanh(fmaf(dt * A21, q1, u0));
+      const float q2 = mv16(Mw, h2, cq);
+      const float h3 = fast_tanh(fmaf(dt, A31 * q1 + A32 * q2, u0));
+      const float q3 = mv16(Mw, h3, cq);
+      const float h4 = fast_tanh(fmaf(dt, A41 * q1 + A42 * q2 + A43 * q3, u0));
+      const float q4 = mv16(Mw, h4, cq);
+      const float h5 = fast_tanh(fmaf(dt, A51 * q1 + A52 * q2 + A53 * q3 + A54 * q4, u0));
+      const float q5 = mv16(Mw, h5, cq);
+      const float h6 = fast_tanh(fmaf(dt, A61 * q1 + A62 * q2 + A63 * q3 + A64 * q4 + A65 * q5, u0));
+      const float q6 = mv16(Mw, h6, cq);
+      const float u7 = fmaf(dt, B1 * q1 + B3 * q3 + B4 * q4 + B5 * q5 + B6 * q6, u0);
+      const float h7 = fast_tanh(u7);
+      const float Hb = B1 * h1 + B3 * h3 + B4 * h4 + B5 * h5 + B6 * h6;
+      const float He = E1 * h1 + E3 * h3 + E4 * h4 + E5 * h5 + E6 * h6 + E7 * h7;
+      const float y1 = fmaf(dt, mv16(w2, Hb, b2), y0);
+      const float err = dt * mv16(w2, He, 0.f);
+      const float tol = atol + rtol * fmaxf(fabsf(y0), fabsf(y1));
+      const float rr = err / tol;
+      float v[1] = {valid ? rr * rr : 0.f};
+      const float q7 = mv16(Mw, h7, cq);
+      batch_sum<1>(v, &R, par, X);
+      const float ratio = sqrtf(v[0] * inv_count);
+      ++steps;
+      if (ratio <= 1.f) {
+        sy = y0; sdt = dt; sHb = Hb; sh1 = h1; sh7 = h7;
+        sHm = C1 * h1 + C3 * h3 + C4 * h4 + C5 * h5 + C6 * h6 + C7 * h7;
+        seg0 = tcur; seg1 = tcur + dtd;
+        tcur = seg1; y0 = y1; u0 = u7; h1 = h7; q1 = q7;
+      }
+      dtd *= (double)step_factor(ratio);
+    }
+    if (stalled) break;
+    // (the abscissa is formed from the fp32-rounded times, as torchdiffeq does)
+    const float x = ((float)target - (float)seg0) / ((float)seg1 - (float)seg0);
+    float wS, wM, w1c, w7c;
+    interp_weights(x, wS, wM, w1c, w7c);
+    const float Hx = wS * sHb + wM * sHm + w1c * sh1 + w7c * sh7;
+    emit(j, fmaf(sdt, mv16(w2, Hx, b2 * (wS + 0.5f * wM + w1c + w7c)), sy));
+  }
+  if (a.nsteps && wg == 0 && threadIdx.x == 0) a.nsteps[0] = stalled ? -steps - 1 : steps;
+}
+
+struct OdeBwdJobs { gode_ode_bwd_op op[RV_MAX_JOBS]; int32_t nblk[RV_MAX_JOBS]; int32_t count; int32_t direct; };
+
+__global__ void __launch_bounds__(RV_THREADS) ode_dopri5_bwd_valu_kernel(const OdeBwdJobs J) {
+  __shared__ float P[GODE_ODE_NPARAM];
+  __shared__ AdjLdsV lds;
+  __shared__ RedLds R;
+  int job = 0, wg = blockIdx.x;
+  while (job + 1 < J.count && wg >= J.nblk[job]) { wg -= J.nblk[job]; ++job; }
+  const gode_ode_bwd_op a = J.op[job];
+  AdjV S;
+  S.lane = threadIdx.x & 63; S.wave = threadIdx.x >> 6; S.i = S.lane & 15; S.tl = S.lane >> 4;
+  S.L = &lds; S.R = &R; S.par = 0;
+  const int i = S.i, tl = S.tl, wave = S.wave;
+  const int n0 = wg * RV_TRAJ, n = n0 + wave * 4 + tl;
+  const bool valid = n < a.N;
+  S.valid = valid;
+  const int T = a.T;
+  S.inv_ya = 1.f / ((float)a.N * 16.f);
+  S.rtol = a.rtol; S.atol = a.atol;
+  S.X.nwg = J.nblk[job]; S.X.wg = wg; S.X.seq = 0; S.X.counter = a.sync;
+  S.xslots = a.sync ? reinterpret_cast<float*>(a.sync) + XS_HDR : nullptr;
+  S.st[0] = S.st[1] = 0.f; S.gt[0] = S.gt[1] = 0.f;
+  if (threadIdx.x == 0) R.dead = 0;
+  const float x = (valid && a.prenet) ? a.x[(int64_t)n * 16 + i] : 0.f;      // needed by the pre-net backward at the very end
+  stage_ode_params(a.p, a.prenet, P);
+  int src[16];
+  probe_sources(i, src);
+  load_rows(S.w1, P + DP_W1, 16, 0, 0, i, src);
+  load_rows(S.w2, P + DP_W2, 16, 0, 0, i, src);
+  load_cols(S.w1t, P + DP_W1, 16, 0, 0, i, src);
+  load_cols(S.w2t, P + DP_W2, 16, 0, 0, i, src);
+  S.b1 = P[DP_B1 + i]; S.b2 = P[DP_B2 + i];
+
+  const int tsel = (a.sel_t && valid) ? a.sel_t[n] : -1;
+  auto upstream = [&](int t) -> float {
+    if (!valid) return 0.f;
+    if (a.sel_t == nullptr) return a.gz[((int64_t)n * T + t) * a.zcols + i];
+    return t == tsel ? a.gz[(int64_t)n * a.zcols + i] : 0.f;
+  };
+  float adj = upstream(T - 1);
+  int steps = 0;
+  for (int it = T - 1; it >= 1; --it) {
+    const float y = valid ? a.traj[((int64_t)n * T + it) * 16 + i] : 0.f;
+    S.solve(y, adj, -(double)a.tout[it], -(double)a.tout[it - 1], steps, it == T - 1);
+    if (steps < 0) break;
+    adj = adj + upstream(it - 1);
+  }
+  if (a.nsteps && wg == 0 && threadIdx.x == 0) a.nsteps[0] = steps;
+  // ---- output row: [Wa 1024 | ba 64 | Wb 1024 | bb 16 | W1 256 | b1 16 | W2 256 | b2 16].  One launch of ONE workgroup writes (or
+  // adds to) grads directly; otherwise one row of `work` per workgroup (the ODEFunc block holds the BATCH total in every
+  // workgroup: row 0 carries it, the others zeros), added by ode_rows_kernel
+  float* out = J.direct ? a.grads : a.work + (int64_t)wg * GODE_ODE_NPARAM;
+  const bool acc_out = J.direct && a.accumulate;
+  auto put = [&](int dst, float v) { out[dst] = acc_out ? out[dst] + v : v; };
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = (int)threadIdx.x + RV_THREADS * k;
+    if (e < TH_N) put(DP_W1 + e, (wg == 0 && steps >= 0) ? S.gt[k] : 0.f);     // TH_* order == W1, b1, W2, b2
+  }
+  if (!a.prenet) {
+    for (int k = threadIdx.x; k < DP_W1; k += RV_THREADS) put(k, 0.f);
+    return;
+  }
+  // ---- pre-net backward; adj = dL/d(pre-net output).  With one (trajectory, feature) value per lane the batch sums of
+  // outer products are one MFMA per 16x16 chunk (k = the wave's 4 trajectories); the waves' images meet in LDS per chunk.
+  float hpre[4];
+  float acc = P[DP_BB + i];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    W16 wa, wb;
+    load_rows(wa, P + DP_WA, 16, 16 * m, 0, i, src);
+    load_rows(wb, P + DP_WB, 64, 0, 16 * m, i, src);
+    hpre[m] = mv16(wa, x, P[DP_BA + 16 * m + i]);
+    acc = mv16(wb, lrelu1(hpre[m]), acc);
+  }
+  const float g0 = valid ? (acc > 0.f ? adj : 0.2f * adj) : 0.f;
+#pragma unroll 1
+  for (int m = 0; m < 4; ++m) {
+    W16 wbt;
+    load_cols(wbt, P + DP_WB, 64, 0, 16 * m, i, src);      // (Wb chunk)^T
+    const float tt = mv16(wbt, g0, 0.f);
+    const float gh = valid ? (hpre[m] > 0.f ? tt : 0.2f * tt) : 0.f;
+    const f32x4 dWb = MFMA16(g0, lrelu1(hpre[m]), zero4());   // [i][j] = sum_n g0_i lrelu(hpre_m)_j -> Wb[i][16m + j]
+    const f32x4 dWa = MFMA16(gh, x, zero4());                 // [i][j] = sum_n gh_i x_j              -> Wa[16m + i][j]
+    float* im = &lds.img[wave][0][0];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      im[(4 * tl + r) * 16 + i] = dWb[r];
+      im[256 + (4 * tl + r) * 16 + i] = dWa[r];
+    }
+    const float sba = traj_sum(gh), sbb = traj_sum(g0);
+    if (tl == 0) { im[512 + i] = sba; im[528 + i] = sbb; }
+    __syncthreads();
+    for (int k = threadIdx.x; k < TH_N; k += RV_THREADS) {
+      const float v = S.img_total(0, k);
+      if (k < 256) put(DP_WB + (k >> 4) * 64 + 16 * m + (k & 15), v);
+      else if (k < 512) put(DP_WA + (16 * m + ((k - 256) >> 4)) * 16 + (k & 15), v);
+      else if (k < 528) put(DP_BA + 16 * m + (k - 512), v);
+      else if (m == 0) put(DP_BB + (k - 528), v);
+    }
+  }
+}
+
+// rows of `work` (ops sharing a grads pointer, in array order) -> grads, fixed order; row length 2,672
+struct OdeRowsArgs { const float* work[RV_MAX_JOBS]; int32_t rows[RV_MAX_JOBS]; int32_t count, accumulate; float* grads; };
+__global__ void __launch_bounds__(256) ode_rows_kernel(const OdeRowsArgs A) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= GODE_ODE_NPARAM) return;
+  float s = 0.f;
+  for (int j = 0; j < A.count; ++j)
+    for (int b = 0; b < A.rows[j]; ++b) s += A.work[j][(int64_t)b * GODE_ODE_NPARAM + k];
+  A.grads[k] = A.accumulate ? A.grads[k] + s : s;
+}
+
+int gode_launch_ode_dopri5(const gode_ode_fwd_op* op, hipStream_t st);          // odernn.hip (MFMA fallback)
+int gode_launch_ode_dopri5_bwd_mfma(const gode_ode_bwd_op* op, hipStream_t st); // ode.hip (MFMA fallback incl. its reduce)
+
+static bool ode5_fwd_ok(const gode_ode_fwd_op* op) {
+  if (!op || op->method != 1 || !op->x || !op->z || !op->tout || op->N <= 0 || op->T < 1 || !(op->rtol > 0.f) || !(op->atol >= 0.f)) return false;
+  if (op->zcols < 68 || op->zcols % 4 != 0) return false;
+  if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2) return false;
+  if (op->prenet && (!op->p.Wa || !op->p.ba || !op->p.Wb || !op->p.bb)) return false;
+  return true;
+}
+
+// `count` (<= 8) dopri5 latent solves (method == 1 ops) in one launch (ops: HOST array)
+extern "C" int gode_ode_fwd_multi(const gode_ode_fwd_op* ops, int32_t count, void* stream) {
+  if (!ops || count < 1 || count > RV_MAX_JOBS) return GODE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  OdeFwdJobs J;
+  J.count = 0;
+  int spinning = 0;
+  for (int k = 0; k < count; ++k) {
+    if (!ode5_fwd_ok(&ops[k])) return GODE_E_ARG;
+    const int nblk = (ops[k].N + RV_TRAJ - 1) / RV_TRAJ;
+    if (nblk > 1 && ops[k].sync) spinning += nblk;
+  }
+  for (int k = 0; k < count; ++k) {
+    const int nblk = (ops[k].N + RV_TRAJ - 1) / RV_TRAJ;
+    if (nblk > 1 && (!ops[k].sync || spinning > RV_MAX_WGS)) {       // no exchange buffer, or too many workgroups to be co-resident
+      const int rc = gode_launch_ode_dopri5(&ops[k], st);
+      if (rc) return rc;
+      continue;
+    }
+    if (nblk > 1) {
+      const hipError_t e = hipMemsetAsync(ops[k].sync, 0, XS_HDR * sizeof(int32_t), st);
+      if (e != hipSuccess) return (int)e;
+    }
+    J.op[J.count] = ops[k]; J.nblk[J.count] = nblk; J.count += 1;
+  }
+  if (J.count == 0) return 0;
+  int grid = 0;
+  for (int k = 0; k < J.count; ++k) grid += J.nblk[k];
+  hipLaunchKernelGGL(ode_dopri5_fwd_valu_kernel, dim3(grid), dim3(RV_THREADS), 0, st, J);
+  GODE_LAUNCH_CHECK();
+  return 0;
+}
+
+static int ode5_bwd_launch(const gode_ode_bwd_op* ops, int count, hipStream_t st) {
+  OdeBwdJobs J;
+  J.count = count;
+  int grid = 0;
+  for (int k = 0; k < count; ++k) {
+    const int nblk = (ops[k].N + RV_TRAJ - 1) / RV_TRAJ;
+    if (nblk > 1) {
+      const hipError_t e = hipMemsetAsync(ops[k].sync, 0, XS_HDR * sizeof(int32_t), st);
+      if (e != hipSuccess) return (int)e;
+    }
+    J.op[k] = ops[k]; J.nblk[k] = nblk;
+    grid += nblk;
+  }
+  J.direct = (count == 1 && grid == 1) ? 1 : 0;
+  hipLaunchKernelGGL(ode_dopri5_bwd_valu_kernel, dim3(grid), dim3(RV_THREADS), 0, st, J);
+  GODE_LAUNCH_CHECK();
+  if (J.direct) return 0;
+  bool done[RV_MAX_JOBS] = {false};
+  for (int k = 0; k < count; ++k) {
+    if (done[k]) continue;
+    OdeRowsArgs A;
+    A.count = 0; A.grads = ops[k].grads; A.accumulate = ops[k].accumulate;
+    for (int j = k; j < count; ++j) {
+      if (!done[j] && ops[j].grads == ops[k].grads) { A.work[A.count] = ops[j].work; A.rows[A.count] = J.nblk[j]; A.count += 1; done[j] = true; }
+    }
+    hipLaunchKernelGGL(ode_rows_kernel, dim3((GODE_ODE_NPARAM + 255) / 256), dim3(256), 0, st, A);
+    GODE_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// the adaptive adjoints (method == 1, substeps == 0) of `count` (<= 8) dopri5 solves in one launch
+extern "C" int gode_ode_bwd_multi(const gode_ode_bwd_op* ops, int32_t count, void* stream) {
+  if (!ops || count < 1 || count > RV_MAX_JOBS) return GODE_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int spinning = 0;
+  bool fallback = false;
+  for (int k = 0; k < count; ++k) {
+    const gode_ode_bwd_op* op = &ops[k];
+    if (op->method != 1 || op->substeps != 0 || !op->traj || !op->gz || !op->work || !op->grads || !op->tout || op->N <= 0 || op->T < 1 ||
+        !(op->rtol > 0.f) || !(op->atol >= 0.f) || op->zcols < 16 || op->zcols % 4 != 0)
+      return GODE_E_ARG;
+    if (!op->p.W1 || !op->p.b1 || !op->p.W2 || !op->p.b2) return GODE_E_ARG;
+    if (op->prenet && (!op->x || !op->p.Wa || !op->p.ba || !op->p.Wb || !op->p.bb)) return GODE_E_ARG;
+    const int nblk = (op->N + RV_TRAJ - 1) / RV_TRAJ;
+    if (nblk > 1) { if (!op->sync) fallback = true; else spinning += nblk; }
+  }
+  if (spinning > RV_MAX_WGS) fallback = true;
+  if (!fallback) return ode5_bwd_launch(ops, count, st);
+  for (int k = 0; k < count; ++k) {       // in array order, each with its own accumulate flag
+    const int nblk = (ops[k].N + RV_TRAJ - 1) / RV_TRAJ;
+    const bool mfma = nblk > 1 && (!ops[k].sync || spinning > RV_MAX_WGS);
+    const int rc = mfma ? gode_launch_ode_dopri5_bwd_mfma(&ops[k], st) : ode5_bwd_launch(&ops[k], 1, st);
+    if (rc) return rc;
+  }
+  return 0;
+}

@@ -222,6 +222,11 @@ class _GenPlan:
                 # (adjoint_substeps == 0, gode_ode_bwd method 1) or with `adjoint_substeps` fixed Kutta-3/8 steps
                 self._tout = torch.linspace(0, 1, self.T).float().to(self.device)
                 self._nsteps = torch.zeros((self.n + 63) // 64, dtype=torch.int32, device=self.device)
+                # more than one workgroup (32 trajectories each): whole-batch error norm through these words
+                ns = L.lib().gode_odernn_sync_size(self.n)
+                self._sync_f = torch.zeros(ns, dtype=torch.int32, device=self.device) if ns else None
+                self._sync_b = torch.zeros(ns, dtype=torch.int32, device=self.device) if ns else None
+                self.fwd_op.sync, self.bwd_op.sync = dptr(self._sync_f), dptr(self._sync_b)
                 self.fwd_op.method, self.fwd_op.rtol, self.fwd_op.atol = 1, float(self.gen.ode_rtol), float(self.gen.ode_atol)
                 self.fwd_op.tout, self.fwd_op.nsteps = dptr(self._tout), dptr(self._nsteps)
                 self.bwd_op.method, self.bwd_op.rtol, self.bwd_op.atol = 1, float(self.gen.ode_rtol), float(self.gen.ode_atol)
@@ -316,7 +321,15 @@ class _GenPlan:
             self.bwd_op.gz = gz.data_ptr()
             self.bwd_op.grads = off
             self.bwd_op.accumulate = 1 if acc else 0
-            L.run_one(self.bwd_op, stream_ptr())
+            batch = getattr(self.gen, "_adjoint_batch", None)
+            if batch is not None and self.gen.ode_method == "dopri5" and self.gen.adjoint_substeps == 0:
+                # adaptive adjoints of the video and the image path: one launch (see _RnnGenPlan.backward)
+                batch["ops"].append(self.bwd_op)
+                batch["keep"].append(gz)
+                if len(batch["ops"]) >= batch["expect"]:
+                    self.gen.flush_adjoints()
+            else:
+                L.run_one(self.bwd_op, stream_ptr())
             self.busy = False
             return None, None
         flat, views, gz = self.stack.backward(gout, need_input_grad=True)
@@ -623,8 +636,27 @@ class VideoGenerator(nn.Module):
 
     def _launch_latents(self, plans):
         st = stream_ptr()
+        if self.ode_method == "dopri5":     # adaptive solves, one workgroup each at the config sizes: one launch per 8
+            for k in range(0, len(plans), 8):
+                chunk = plans[k:k + 8]
+                arr = (L.OdeFwdOp * len(chunk))(*[p.fwd_op for p in chunk])
+                L.call("ode_fwd_multi", lambda: L.check(L.lib().gode_ode_fwd_multi(arr, len(chunk), st), "gode_ode_fwd_multi"))
+            return
         for p in plans:
             p.fwd_prog.run(st)
+
+    def flush_adjoints(self):
+        """Launch the adaptive adjoints collected during a backward pass (GanTrainer.g_step: video + image path)."""
+        batch = getattr(self, "_adjoint_batch", None)
+        if not batch or not batch["ops"]:
+            return
+        ops = batch["ops"]
+        st = stream_ptr()
+        for k in range(0, len(ops), 8):
+            chunk = ops[k:k + 8]
+            arr = (L.OdeBwdOp * len(chunk))(*chunk)
+            L.call("ode_bwd_multi", lambda: L.check(L.lib().gode_ode_bwd_multi(arr, len(chunk), st), "gode_ode_bwd_multi"))
+        batch["ops"], batch["keep"] = [], []
 
     def discard_prefetched(self):
         """Drop latents that were prefetched but will not be consumed (an exception in the middle of an iteration)."""

@@ -189,8 +189,15 @@ typedef struct gode_ode_fwd_op {
    * over the trajectories of a workgroup (<= 64; torchdiffeq: over the whole batch).  nsteps[ceil(N/64)] (nullable)
    * receives the number of trial steps.  method 0: fixed-grid rk4 (above). */
   int32_t method, pad2_; float rtol, atol; const float* tout; int32_t* nsteps;
+  /* method 1 with N > 32: >= gode_odernn_sync_size(N) words through which the workgroups exchange the whole-batch error norm
+   * (see the ODE-RNN ops below; NULL or more than GODE_ODERNN_SYNC_MAX_N trajectories per launch: one norm per
+   * 64-trajectory workgroup, nsteps per such workgroup).  With it nsteps[0] = trial steps of the call (negative: stalled). */
+  int32_t* sync;
 } gode_ode_fwd_op;
 int gode_ode_fwd(const gode_ode_fwd_op* op, void* stream);
+/* `count` (<= 8) independent method-1 solves in ONE launch (ops: HOST array): the dopri5 counterpart of
+ * gode_odernn_fwd_multi below */
+int gode_ode_fwd_multi(const gode_ode_fwd_op* ops, int32_t count, void* stream);
 /* adjoint backward (torchdiffeq odeint_adjoint semantics: per output interval ONE reverse-time RK4(3/8) step of
  * (y, a, g_theta), y reset to the stored trajectory, a += upstream grad) followed by the pre-net backward.
  * gz[rows][zcols]: gradient wrt the latent rows (only the 16 motion columns are read).  Parameter gradients are
@@ -210,10 +217,15 @@ typedef struct gode_ode_bwd_op {
    * the theta state is carried across the output intervals, the solver restarts on each.  method 1 with substeps > 0:
    * the same adjoint discretised with `substeps` fixed Kutta-3/8 steps per interval (round-1 behaviour; dt required). */
   int32_t method, pad_; float rtol, atol; const float* tout;
-  int32_t* nsteps;   /* nullable, adaptive adjoint only: [ceil(N/64)] trial steps of the adjoint call per workgroup; a negative
-                        entry reports a call that stalled (trial-step limit / step-size underflow: torchdiffeq asserts there) */
+  int32_t* nsteps;   /* nullable, adaptive adjoint only: trial steps of the adjoint call (nsteps[0]; without `sync` and N > 32:
+                        [ceil(N/64)], one per workgroup); a negative entry reports a call that stalled (trial-step limit /
+                        step-size underflow: torchdiffeq asserts there) */
+  int32_t* sync;     /* adaptive adjoint with N > 32: as in gode_ode_fwd_op */
 } gode_ode_bwd_op;
 int gode_ode_bwd(const gode_ode_bwd_op* op, void* stream);
+/* the adaptive adjoints (method 1, substeps 0) of `count` (<= 8) solves in one launch; ops sharing a grads pointer are
+ * reduced in array order */
+int gode_ode_bwd_multi(const gode_ode_bwd_op* ops, int32_t count, void* stream);
 int64_t gode_ode_bwd_work_size(int32_t N);
 #define GODE_ODE_NPARAM 2672
 

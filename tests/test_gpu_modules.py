@@ -557,7 +557,7 @@ def test_dopri5_method_against_oracle(tag, mnist):
     passes method='rk4'): torchdiffeq's adaptive solver over the 16 output times with dense-output interpolation, on
     the device in one launch.  PARITY UNPINNED (torchdiffeq is not installed; the reference holds no fixture):
     checked against the oracle's restatement (oracle/ode_ref.py:dopri5_solve + odeint_adjoint, which integrates the
-    adjoint adaptively; the device integrates the same adjoint with 4 fixed Kutta steps per output interval)."""
+    adjoint adaptively, as the device does: csrc/odernn_valu.hip, mixed norm over the whole batch)."""
     g = golden(f"gen_{tag}.npz")
     s = int(g["seed"])
     if mnist:

@@ -123,3 +123,70 @@ def test_odernn_generator_against_oracle():
             assert float(d.median() / (q.grad.norm() / q.grad.numel() ** 0.5)) < 5e-3, k
             assert rel_err(p.grad.cpu(), q.grad) < 5e-2, k
     assert gen.recurrent.weight_hh.grad is not None       # the GRU cell is live in this variant
+
+
+@pytest.mark.parametrize("N,T,prenet", [(16, 16, True), (32, 16, False), (100, 6, True)])
+def test_dopri5_latent_kernels_against_oracle(N, T, prenet):
+    """gode_ode_fwd / gode_ode_bwd with method 1 (ode_method="dopri5" on the plain generators; BASELINE configs[3] wording)
+    through the C ABI: pre-net + ONE adaptive solve over the T output times with dense output, and ONE adjoint call over the
+    T - 1 intervals (theta state carried, solver restarted per interval), against oracle.ode_ref (parity unpinned).  N = 100:
+    four workgroups exchanging the whole-batch norm.  States 2e-5, all eight gradient tensors 1e-4, trial-step counts of the
+    forward call equal to the oracle's up to one borderline decision."""
+    torch.manual_seed(N + T)
+    f = M.OdeRhs(16, 16)
+    pre = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.LeakyReLU(0.2), torch.nn.Linear(64, 16), torch.nn.LeakyReLU(0.2))
+    x = torch.randn(N, 16)
+    tt = torch.linspace(0, 1, T).float()
+    calls = [0]
+    f.register_forward_pre_hook(lambda *_: calls.__setitem__(0, calls[0] + 1))
+    y0 = pre(x) if prenet else x.clone().requires_grad_(True)
+    sol = ode_ref.odeint_adjoint(f, y0, tt, method="dopri5")              # [T, N, 16]
+    ref_trials = (calls[0] - 2) // 6
+    zref = sol.transpose(0, 1)                                            # [N, T, 16]
+    gup = torch.randn(N, T, 16, generator=torch.Generator().manual_seed(3))
+    (zref * gup).sum().backward()
+    params = (list(pre.parameters()) if prenet else []) + list(f.parameters())
+    ref_grads = [p.grad for p in params]
+    # device
+    dev = [p.detach().cuda() for p in params]
+    ptrs = [p.data_ptr() for p in dev]
+    op = L.OdeParams(*(ptrs if prenet else [None] * 4 + ptrs))
+    xd, content, tout = x.cuda(), torch.randn(N, 50).cuda(), tt.cuda()
+    z = torch.full((N * T, 72), float("nan"), device="cuda")
+    traj = torch.empty(N, T, 16, device="cuda")
+    nst = torch.full(((N + 63) // 64,), -7, dtype=torch.int32, device="cuda")
+    nsync = L.lib().gode_odernn_sync_size(N)
+    sync = torch.zeros(max(nsync, 1), dtype=torch.int32, device="cuda")
+    fop = L.OdeFwdOp(p=op, x=xd.data_ptr(), content=content.data_ptr(), dt=None, sel_t=None, z=z.data_ptr(), traj=traj.data_ptr(),
+                     N=N, T=T, substeps=1, prenet=1 if prenet else 0, zcols=72, method=1, rtol=1e-7, atol=1e-9, tout=tout.data_ptr(),
+                     nsteps=nst.data_ptr(), sync=sync.data_ptr() if nsync else None)
+    L.run_one(fop, stream())
+    zz = z.cpu().view(N, T, 72)
+    assert rel_err(traj.cpu(), zref.detach()) < 2e-5 and rel_err(zz[:, :, :16], zref.detach()) < 2e-5
+    assert torch.equal(zz[:, :, 16:66], content.cpu()[:, None, :].expand(N, T, 50))
+    assert abs(int(nst[0]) - ref_trials) <= 1, (int(nst[0]), ref_trials)
+    gz = torch.zeros(N * T, 72, device="cuda")
+    gz.view(N, T, 72)[:, :, :16] = gup.cuda()
+    grads = torch.full((L.ODE_NPARAM,), float("nan"), device="cuda")
+    work = torch.empty(L.lib().gode_ode_bwd_work_size(N), device="cuda")
+    nstb = torch.full(((N + 63) // 64,), -7, dtype=torch.int32, device="cuda")
+    syncb = torch.zeros(max(nsync, 1), dtype=torch.int32, device="cuda")
+    bop = L.OdeBwdOp(p=op, x=xd.data_ptr(), traj=traj.data_ptr(), dt=None, sel_t=None, gz=gz.data_ptr(), work=work.data_ptr(),
+                     grads=grads.data_ptr(), N=N, T=T, substeps=0, prenet=1 if prenet else 0, accumulate=0, zcols=72, method=1,
+                     rtol=1e-7, atol=1e-9, tout=tout.data_ptr(), nsteps=nstb.data_ptr(), sync=syncb.data_ptr() if nsync else None)
+    L.run_one(bop, stream())
+    assert int(nstb[0]) >= T - 1, nstb
+    g = grads.cpu()
+    names = ("Wa", "ba", "Wb", "bb", "W1", "b1", "W2", "b2")
+    offs = (0, 1024, 1088, 2112, 2128, 2384, 2400, 2656)
+    lens = (1024, 64, 1024, 16, 256, 16, 256, 16)
+    k0 = 0 if prenet else 4
+    if not prenet:
+        assert float(g[:2128].abs().max()) == 0.0
+    for name, o, n_, r in zip(names[k0:], offs[k0:], lens[k0:], ref_grads):
+        assert rel_err(g[o:o + n_].view_as(r), r) < 1e-4, (name, rel_err(g[o:o + n_].view_as(r), r))
+    # accumulate flag
+    base = grads.clone()
+    bop.accumulate = 1
+    L.run_one(bop, stream())
+    assert rel_err(grads.cpu(), 2 * base.cpu()) < 1e-6
