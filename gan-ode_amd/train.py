@@ -630,7 +630,7 @@ class GanTrainer:
             return losses[0]
         return torch.stack(losses).mean()
 
-    def d_image_step(self, real_img, _join=True):
+    def d_image_step(self, real_img, _join=True, _defer=False):
         """mnist_moco_ode.py:115-131.  real_img: [B,C,H,W], or a list of such shards (virtual replicas)."""
         shards = _shards(real_img)
         side = self._side
@@ -664,6 +664,8 @@ class GanTrainer:
             losses.append(loss.detach())
         with on_side():
             self._opt_step(self.dis_img, self.img_opt, len(shards))
+            if not _defer:
+                self._flush(self.dis_img)      # called on its own: the update has landed when the call returns
             out = self._mean(losses)
         if _join:
             self._join_side()
@@ -675,7 +677,7 @@ class GanTrainer:
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_pending = False
 
-    def d_video_step(self, real_vid):
+    def d_video_step(self, real_vid, _defer=False):
         """mnist_moco_ode.py:133-150.  real_vid: [B,T,C,H,W], or a list of such shards."""
         shards = _shards(real_vid)
         losses = []
@@ -703,6 +705,8 @@ class GanTrainer:
             loss.backward(gradient=unit_grad(loss.device))
             losses.append(loss.detach())
         self._opt_step(self.dis_vid, self.vid_opt, len(shards))
+        if not _defer:
+            self._flush(self.dis_vid)
         return self._mean(losses)
 
     def g_step(self, B, shards=1):
@@ -746,6 +750,7 @@ class GanTrainer:
             for p in frozen:
                 p.requires_grad_(True)
         self._opt_step(self.gen, self.gen_opt, shards)
+        self._flush(self.gen)              # weights are current when the step returns (checkpoints, the next prefetch)
         return self._mean(losses)
 
     def step(self, real_imgs: Sequence, real_vids: Sequence):
@@ -771,8 +776,9 @@ class GanTrainer:
             self.gen.prefetch_latents(calls)
         try:
             for i in range(self.d_iters):
-                li = self.d_image_step(real_imgs[i], _join=False)     # side stream (see overlap_image_d)
-                lv = self.d_video_step(real_vids[i])
+                # (inside step() the discriminators' optimiser steps are deferred: see overlap_allreduce)
+                li = self.d_image_step(real_imgs[i], _join=False, _defer=True)     # side stream (see overlap_image_d)
+                lv = self.d_video_step(real_vids[i], _defer=True)
             if self._pending:
                 # the G step reads both discriminators: their deferred updates land now (the image discriminator's on its
                 # side stream, where its step ran)
@@ -784,7 +790,6 @@ class GanTrainer:
                 self._flush(self.dis_vid)
             self._join_side()                                         # the G step reads the updated image discriminator
             lg = self.g_step(B, nsh)
-            self._flush(self.gen)          # weights are current when step() returns (checkpoints, the next prefetch)
         except BaseException:
             if hasattr(self.gen, "discard_prefetched"):
                 self.gen.discard_prefetched()
