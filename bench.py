@@ -419,7 +419,8 @@ def _rank_main(a):
     if distributed:
         dist.barrier()       # every rank leaves the collective phase before rank 0 goes off to its single-rank legs
     if rank == 0:
-        roof = _kernel_roofline(gen, live_traffic=not a.no_live_traffic) if a.config == "mnist" else None
+        # (live PMC passes only in single-GPU runs: in a distributed run the other ranks would sit in the final barrier)
+        roof = _kernel_roofline(gen, live_traffic=not a.no_live_traffic and not distributed) if a.config == "mnist" else None
         it_roof = _iteration_roofline(tr, imgs, vids, min(it_ms, it_graph_ms) if it_graph_ms else it_ms) if not distributed else None
         cpu = None if a.no_cpu_baseline or distributed or a.config != "mnist" else _cpu_baseline(threads=G.host_cpu_quota())
         workload = {"mnist": "Rotated-MNIST MoCoGAN+ODE, gen.sample_videos(32): batch 32/GPU, 16x1x28x28, ngf=ndf=64, "
