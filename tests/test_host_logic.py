@@ -76,6 +76,10 @@ def test_no_cpu_fallback():
         G.bce_with_logits_const(torch.zeros(3), 1.0)
     with pytest.raises(RuntimeError):
         gen.ode_fn(None, torch.zeros(1, 16))
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        gen.prefetch_latents([("videos", 2)])
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        gen.sample_z_m(2)
 
 
 def test_sample_images_host_draws_match_oracle_rng_order(monkeypatch):
