@@ -190,3 +190,55 @@ def test_dopri5_latent_kernels_against_oracle(N, T, prenet):
     bop.accumulate = 1
     L.run_one(bop, stream())
     assert rel_err(grads.cpu(), 2 * base.cpu()) < 1e-6
+
+
+def test_odernn_generator_surface_video_len_eval_mode_and_more_than_one_workgroup():
+    """The rest of the drop-in class's surface against the oracle: the video_len argument, 40 videos / 40 images (two
+    workgroups exchanging the whole-batch error norm through the plan's sync words, the image path with row selection),
+    eval mode (running statistics), state_dict round trip into the oracle class."""
+    seed_all(15)
+    gen = G.VideoGeneratorMNISTODERNN(1, 50, 0, 16, 16, ngf=8)
+    ref = M.GeneratorOdeRnn(1, 50, 0, 16, 16, ngf=8, mnist=True)
+    ref.load_state_dict(gen.state_dict())
+    gen.cuda()
+    with torch.no_grad():
+        seed_all(16)
+        v8, _ = gen.sample_videos(3, 8)
+        v40, lab = gen.sample_videos(40)
+        i40, _ = gen.sample_images(40)
+        seed_all(16)
+        r8, _ = ref.sample_videos(3, 8)
+        r40, _ = ref.sample_videos(40)
+        ri40, _ = ref.sample_images(40)
+    assert v8.shape == (3, 1, 8, 28, 28) and v40.shape == (40, 1, 16, 28, 28) and i40.shape == (40, 1, 28, 28)
+    assert lab.dtype == torch.float64 and lab.shape == (40,)
+    assert rel_err(v8.cpu(), r8) < 1e-4 and rel_err(v40.cpu(), r40) < 1e-4 and rel_err(i40.cpu(), ri40) < 1e-4
+    plan = gen._pool.plans[(40, 16, False)][0]
+    assert plan.sync_f is not None and int(plan.nsteps.min()) >= 2          # two workgroups, no stalled frame
+    # running statistics moved identically; eval mode uses them
+    for (k, a), (_, b) in zip(gen.state_dict().items(), ref.state_dict().items()):
+        if "running_" in k:
+            assert rel_err(a.cpu(), b) < 1e-4, k
+        if "num_batches" in k:
+            assert int(a) == int(b), k
+    gen.eval(); ref.eval()
+    with torch.no_grad():
+        seed_all(17)
+        ve, _ = gen.sample_videos(5)
+        seed_all(17)
+        re_, _ = ref.sample_videos(5)
+    assert rel_err(ve.cpu(), re_) < 1e-4
+    # gradients through two workgroups (adjoint exchange incl. the parameter-tensor norms)
+    gen.train(); ref.train()
+    seed_all(18)
+    vg, _ = gen.sample_videos(40)
+    seed_all(18)
+    rg, _ = ref.sample_videos(40)
+    w = torch.randn(vg.shape, generator=torch.Generator().manual_seed(2))
+    (vg * w.cuda()).sum().backward()
+    (rg * w).sum().backward()
+    assert int(plan.nsteps_bwd.min()) >= 2
+    refp = dict(ref.named_parameters())
+    for k in ("ode_fn.fn.0.weight", "ode_fn.fn.0.bias", "ode_fn.fn.2.weight", "ode_fn.fn.2.bias", "recurrent.weight_ih",
+              "recurrent.weight_hh", "recurrent.bias_ih", "recurrent.bias_hh"):
+        assert rel_err(dict(gen.named_parameters())[k].grad.cpu(), refp[k].grad) < 5e-3, k
