@@ -376,7 +376,41 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(const WgradArgs a, int 
     for (int j = 0; j < THIN_MAXKT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 ysc = {1, 1, 1, 1}, ysh = {0, 0, 0, 0};
     if (cok && a.scale && a.xform_on_y) { ysc = *reinterpret_cast<const f32x4*>(a.scale + c4 * 4); ysh = *reinterpret_cast<const f32x4*>(a.shift + c4 * 4); }
-    if (cok) {
+    if ((CL & 15) == 0) {
+      // Shared gathers (round 3): the 16 channel lanes of a DPP row work on the SAME position, and each used to gather all
+      // Kt x values itself (Kt bounds-checked scalar loads of the same addresses in 16 lanes: the kernel was bound by those
+      // ~20 instructions per tap, 39 us for the 27 MB of the MNIST video discriminator's first layer).  Now lane j of a row
+      // gathers tap j only (its tap coordinates are fixed for the whole launch) and the row reads the Kt values from each
+      // other (ds_bpermute): ~2.5x fewer instructions per position.
+      const int lj = tid & 15;
+      const bool tap_ok = lj < Kt;
+      int tci = 0, tkw = 0, tkh = 0, tkd = 0;
+      if (tap_ok) { int tap = lj / g.Ci; tci = lj - tap * g.Ci; tkw = tap % g.kw; tkh = (tap / g.kw) % g.kh; tkd = tap / (g.kw * g.kh); }
+      float xsc = 1.f, xsh = 0.f;
+      if (tap_ok && a.scale && !a.xform_on_y) { xsc = a.scale[tci]; xsh = a.shift[tci]; }
+      const bool xf = !a.xform_on_y;
+      for (int m = m0 + ml; m < m1; m += ML) {       // (ml < ML always here: CL * ML == 256)
+        f32x4 yv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c4 < C4) {
+          yv = *reinterpret_cast<const f32x4*>(a.y + (int64_t)m * g.Co + c4 * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { float t = yv[e] * ysc[e] + ysh[e]; yv[e] = t > 0.f ? t : t * yneg; }
+        }
+        const uint32_t t1 = fdiv((uint32_t)m, a.dWo), qw = m - t1 * g.Wo;
+        const uint32_t t2 = fdiv(t1, a.dHo), qh = t1 - t2 * g.Ho;
+        const uint32_t img = fdiv(t2, a.dDo), qd = t2 - img * g.Do;
+        const int id = (int)qd * g.sd - g.pd + tkd, ih = (int)qh * g.sh - g.ph + tkh, iw = (int)qw * g.sw - g.pw + tkw;
+        float xmine = 0.f;
+        if (tap_ok && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi) {
+          xmine = a.x[(int)img * a.xsN + id * a.xsD + ih * a.xsH + iw * a.xsW + tci * a.xsC];
+          if (xf) { xmine = xmine * xsc + xsh; xmine = xmine > 0.f ? xmine : xmine * xneg; }
+        }
+#pragma unroll
+        for (int j = 0; j < THIN_MAXKT; ++j) {
+          if (j < Kt) acc[j] += yv * __shfl(xmine, j, 16);      // (Kt is launch-uniform)
+        }
+      }
+    } else if (cok) {
       for (int m = m0 + ml; m < m1; m += ML) {
         f32x4 yv = *reinterpret_cast<const f32x4*>(a.y + (int64_t)m * g.Co + c4 * 4);
 #pragma unroll
