@@ -274,18 +274,18 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_fwd_valu_kernel(const RnnFw
     const float e = valid ? a.noise[((int64_t)(t + 1) * a.N + n) * 16 + i] : 0.f;
     // ---- h' = y(1), y' = f(y), y(0) = h.  The clock and the step size are fp64, as torchdiffeq keeps them.
     float y0 = h;
-    float u0 = mv16(w1, y0, b1);
+    float u0 = mv16c(w1, y0, b1);
     float h1 = fast_tanh(u0);
-    float q1 = mv16(Mw, h1, cq);
+    float q1 = mv16c(Mw, h1, cq);
     double dtd;
     {   // torchdiffeq _select_initial_step (order 4)
-      const float f0 = mv16(w2, h1, b2);
+      const float f0 = mv16c(w2, h1, b2);
       const float sc = atol + fabsf(y0) * rtol;
       float v[2] = {valid ? (y0 / sc) * (y0 / sc) : 0.f, valid ? (f0 / sc) * (f0 / sc) : 0.f};
       batch_sum<2>(v, &R, par, X);
       const float d0 = sqrtf(v[0] * inv_count), d1 = sqrtf(v[1] * inv_count);
       const float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
-      const float df = mv16(w2, fast_tanh(fmaf(h0, q1, u0)) - h1, 0.f);          // f(y0 + h0 f0) - f0
+      const float df = mv16c(w2, fast_tanh(fmaf(h0, q1, u0)) - h1, 0.f);          // f(y0 + h0 f0) - f0
       float w[1] = {valid ? (df / sc) * (df / sc) : 0.f};
       batch_sum<1>(w, &R, par, X);
       const float d2 = sqrtf(w[0] * inv_count) / h0;
@@ -303,15 +303,15 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_fwd_valu_kernel(const RnnFw
 #endif
       const float dt = (float)dtd;
       const float h2 = fast_tanh(fmaf(dt * A21, q1, u0));
-      const float q2 = mv16(Mw, h2, cq);
+      const float q2 = mv16c(Mw, h2, cq);
       const float h3 = fast_tanh(fmaf(dt, A31 * q1 + A32 * q2, u0));
-      const float q3 = mv16(Mw, h3, cq);
+      const float q3 = mv16c(Mw, h3, cq);
       const float h4 = fast_tanh(fmaf(dt, A41 * q1 + A42 * q2 + A43 * q3, u0));
-      const float q4 = mv16(Mw, h4, cq);
+      const float q4 = mv16c(Mw, h4, cq);
       const float h5 = fast_tanh(fmaf(dt, A51 * q1 + A52 * q2 + A53 * q3 + A54 * q4, u0));
-      const float q5 = mv16(Mw, h5, cq);
+      const float q5 = mv16c(Mw, h5, cq);
       const float h6 = fast_tanh(fmaf(dt, A61 * q1 + A62 * q2 + A63 * q3 + A64 * q4 + A65 * q5, u0));
-      const float q6 = mv16(Mw, h6, cq);
+      const float q6 = mv16c(Mw, h6, cq);
       const float u7 = fmaf(dt, B1 * q1 + B3 * q3 + B4 * q4 + B5 * q5 + B6 * q6, u0);
       const float h7 = fast_tanh(u7);
 #ifdef GODE_ODE_STAMPS
@@ -320,12 +320,12 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_fwd_valu_kernel(const RnnFw
 #endif
       const float Hb = B1 * h1 + B3 * h3 + B4 * h4 + B5 * h5 + B6 * h6;
       const float He = E1 * h1 + E3 * h3 + E4 * h4 + E5 * h5 + E6 * h6 + E7 * h7;
-      const float y1 = fmaf(dt, mv16(w2, Hb, b2), y0);
-      const float err = dt * mv16(w2, He, 0.f);
+      const float y1 = fmaf(dt, mv16c(w2, Hb, b2), y0);
+      const float err = dt * mv16c(w2, He, 0.f);
       const float tol = atol + rtol * fmaxf(fabsf(y0), fabsf(y1));
       const float rr = err / tol;
       float v[1] = {valid ? rr * rr : 0.f};
-      const float q7 = mv16(Mw, h7, cq);            // next step's q1 if this one is accepted: issued under the sum's latency
+      const float q7 = mv16c(Mw, h7, cq);            // next step's q1 if this one is accepted: issued under the sum's latency
 #ifdef GODE_ODE_STAMPS
       asm volatile("" ::"v"(q7), "v"(v[0]));
       const long long sC = __builtin_amdgcn_s_memtime();
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_fwd_valu_kernel(const RnnFw
           interp_weights(x, wS, wM, w1c, w7c);
           const float Hm = C1 * h1 + C3 * h3 + C4 * h4 + C5 * h5 + C6 * h6 + C7 * h7;
           const float Hx = wS * Hb + wM * Hm + w1c * h1 + w7c * h7;
-          yend = fmaf(dt, mv16(w2, Hx, b2 * (wS + 0.5f * wM + w1c + w7c)), y0);
+          yend = fmaf(dt, mv16c(w2, Hx, b2 * (wS + 0.5f * wM + w1c + w7c)), y0);
           break;
         }
         tcur += dtd; y0 = y1; u0 = u7; h1 = h7; q1 = q7;
@@ -359,9 +359,9 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_fwd_valu_kernel(const RnnFw
     if (stalled) return;              // uniform over the workgroup (and, through the shared norm, over the call)
     if (valid && a.hp) a.hp[((int64_t)n * T + t) * 16 + i] = yend;
     // ---- GRUCell(e_t, h')
-    const float r = fast_sigmoid(mv16(wih[0], e, bih[0]) + mv16(whh[0], yend, bhh[0]));
-    const float zg = fast_sigmoid(mv16(wih[1], e, bih[1]) + mv16(whh[1], yend, bhh[1]));
-    const float nn = fast_tanh(mv16(wih[2], e, bih[2]) + r * mv16(whh[2], yend, bhh[2]));
+    const float r = fast_sigmoid(mv16c(wih[0], e, bih[0]) + mv16c(whh[0], yend, bhh[0]));
+    const float zg = fast_sigmoid(mv16c(wih[1], e, bih[1]) + mv16c(whh[1], yend, bhh[1]));
+    const float nn = fast_tanh(mv16c(wih[2], e, bih[2]) + r * mv16c(whh[2], yend, bhh[2]));
     h = (1.f - zg) * nn + zg * yend;
     if (valid) {
       if (a.hs) a.hs[((int64_t)n * (T + 1) + t + 1) * 16 + i] = h;
@@ -480,11 +480,11 @@ struct AdjV {
 
   // reversed-time augmented dynamics at (y, a): dy = -f(y), da = +a^T df/dy; h and du are the operands of the theta terms
   __device__ __forceinline__ void eval(float y, float a, float& ky, float& ka, float& h, float& du) {
-    h = fast_tanh(mv16(w1, y, b1));
-    const float fv = mv16(w2, h, b2);
-    const float v = mv16(w2t, a, 0.f);
+    h = fast_tanh(mv16c(w1, y, b1));
+    const float fv = mv16c(w2, h, b2);
+    const float v = mv16c(w2t, a, 0.f);
     du = v * (1.f - h * h);
-    ka = mv16(w1t, du, 0.f);
+    ka = mv16c(w1t, du, 0.f);
     ky = -fv;
   }
   // A += c * (theta dynamics at a stage):  dW2 += c a (x) h,  dW1 += c du (x) y,  db2 += c a,  db1 += c du
@@ -821,9 +821,9 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_bwd_valu_kernel(const RnnBw
       for (int q = 0; q < 3; ++q) {
         W16 w;
         load_rows(w, GP + GP_WIH, GP_LD, 16 * q, 0, i, src);
-        gi[q] = mv16(w, e, P[TH_N + 16 * q + i]);
+        gi[q] = mv16c(w, e, P[TH_N + 16 * q + i]);
         load_rows(w, GP + GP_WHH, GP_LD, 16 * q, 0, i, src);
-        hh[q] = mv16(w, hp, P[TH_N + 48 + 16 * q + i]);
+        hh[q] = mv16c(w, hp, P[TH_N + 48 + 16 * q + i]);
       }
       const float r = fast_sigmoid(gi[0] + hh[0]);
       const float zg = fast_sigmoid(gi[1] + hh[1]);
@@ -839,7 +839,7 @@ __global__ void __launch_bounds__(RV_THREADS) odernn_bwd_valu_kernel(const RnnBw
       for (int q = 0; q < 3; ++q) {
         W16 wt;
         load_cols(wt, GP + GP_WHH, GP_LD, 16 * q, 0, i, src);      // (Whh_q)^T
-        adj = mv16(wt, dgh[q], adj);
+        adj = mv16c(wt, dgh[q], adj);
         // this frame's parameter-gradient terms of gate q: the wave's outer-product sums (one MFMA each: the per-lane values
         // are the A / B operands for k = the wave's 4 trajectories) meet in LDS and are added to the thread-owned totals
         const f32x4 pWih = MFMA16(dgi[q], e, zero4()), pWhh = MFMA16(dgh[q], hp, zero4());
@@ -1050,8 +1050,8 @@ __global__ void __launch_bounds__(RV_THREADS) ode_dopri5_fwd_valu_kernel(const O
       W16 wa, wb;
       load_rows(wa, P + DP_WA, 16, 16 * m, 0, i, src);
       load_rows(wb, P + DP_WB, 64, 0, 16 * m, i, src);
-      const float hh = lrelu1(mv16(wa, y0, P[DP_BA + 16 * m + i]));
-      acc = mv16(wb, hh, acc);
+      const float hh = lrelu1(mv16c(wa, y0, P[DP_BA + 16 * m + i]));
+      acc = mv16c(wb, hh, acc);
     }
     y0 = lrelu1(acc);
   }
@@ -1069,18 +1069,18 @@ __global__ void __launch_bounds__(RV_THREADS) ode_dopri5_fwd_valu_kernel(const O
   };
   emit(0, y0);
 
-  float u0 = mv16(w1, y0, b1);
+  float u0 = mv16c(w1, y0, b1);
   float h1 = fast_tanh(u0);
-  float q1 = mv16(Mw, h1, cq);
+  float q1 = mv16c(Mw, h1, cq);
   double dtd;
   {   // torchdiffeq _select_initial_step (order 4)
-    const float f0 = mv16(w2, h1, b2);
+    const float f0 = mv16c(w2, h1, b2);
     const float sc = atol + fabsf(y0) * rtol;
     float v[2] = {valid ? (y0 / sc) * (y0 / sc) : 0.f, valid ? (f0 / sc) * (f0 / sc) : 0.f};
     batch_sum<2>(v, &R, par, X);
     const float d0 = sqrtf(v[0] * inv_count), d1 = sqrtf(v[1] * inv_count);
     const float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
-    const float df = mv16(w2, fast_tanh(fmaf(h0, q1, u0)) - h1, 0.f);
+    const float df = mv16c(w2, fast_tanh(fmaf(h0, q1, u0)) - h1, 0.f);
     float w[1] = {valid ? (df / sc) * (df / sc) : 0.f};
     batch_sum<1>(w, &R, par, X);
     const float d2 = sqrtf(w[0] * inv_count) / h0;
@@ -1098,25 +1098,25 @@ __global__ void __launch_bounds__(RV_THREADS) ode_dopri5_fwd_valu_kernel(const O
       if (R.dead || steps >= RV_MAX_TRIALS || !(tcur + dtd > tcur)) { stalled = true; break; }
       const float dt = (float)dtd;
       const float h2 = fast_tanh(fmaf(dt * A21, q1, u0));
-      const float q2 = mv16(Mw, h2, cq);
+      const float q2 = mv16c(Mw, h2, cq);
       const float h3 = fast_tanh(fmaf(dt, A31 * q1 + A32 * q2, u0));
-      const float q3 = mv16(Mw, h3, cq);
+      const float q3 = mv16c(Mw, h3, cq);
       const float h4 = fast_tanh(fmaf(dt, A41 * q1 + A42 * q2 + A43 * q3, u0));
-      const float q4 = mv16(Mw, h4, cq);
+      const float q4 = mv16c(Mw, h4, cq);
       const float h5 = fast_tanh(fmaf(dt, A51 * q1 + A52 * q2 + A53 * q3 + A54 * q4, u0));
-      const float q5 = mv16(Mw, h5, cq);
+      const float q5 = mv16c(Mw, h5, cq);
       const float h6 = fast_tanh(fmaf(dt, A61 * q1 + A62 * q2 + A63 * q3 + A64 * q4 + A65 * q5, u0));
-      const float q6 = mv16(Mw, h6, cq);
+      const float q6 = mv16c(Mw, h6, cq);
       const float u7 = fmaf(dt, B1 * q1 + B3 * q3 + B4 * q4 + B5 * q5 + B6 * q6, u0);
       const float h7 = fast_tanh(u7);
       const float Hb = B1 * h1 + B3 * h3 + B4 * h4 + B5 * h5 + B6 * h6;
       const float He = E1 * h1 + E3 * h3 + E4 * h4 + E5 * h5 + E6 * h6 + E7 * h7;
-      const float y1 = fmaf(dt, mv16(w2, Hb, b2), y0);
-      const float err = dt * mv16(w2, He, 0.f);
+      const float y1 = fmaf(dt, mv16c(w2, Hb, b2), y0);
+      const float err = dt * mv16c(w2, He, 0.f);
       const float tol = atol + rtol * fmaxf(fabsf(y0), fabsf(y1));
       const float rr = err / tol;
       float v[1] = {valid ? rr * rr : 0.f};
-      const float q7 = mv16(Mw, h7, cq);
+      const float q7 = mv16c(Mw, h7, cq);
       batch_sum<1>(v, &R, par, X);
       const float ratio = sqrtf(v[0] * inv_count);
       ++steps;
@@ -1134,7 +1134,7 @@ __global__ void __launch_bounds__(RV_THREADS) ode_dopri5_fwd_valu_kernel(const O
     float wS, wM, w1c, w7c;
     interp_weights(x, wS, wM, w1c, w7c);
     const float Hx = wS * sHb + wM * sHm + w1c * sh1 + w7c * sh7;
-    emit(j, fmaf(sdt, mv16(w2, Hx, b2 * (wS + 0.5f * wM + w1c + w7c)), sy));
+    emit(j, fmaf(sdt, mv16c(w2, Hx, b2 * (wS + 0.5f * wM + w1c + w7c)), sy));
   }
   if (a.nsteps && wg == 0 && threadIdx.x == 0) a.nsteps[0] = stalled ? -steps - 1 : steps;
 }
@@ -1211,15 +1211,15 @@ __global__ void __launch_bounds__(RV_THREADS) ode_dopri5_bwd_valu_kernel(const O
     W16 wa, wb;
     load_rows(wa, P + DP_WA, 16, 16 * m, 0, i, src);
     load_rows(wb, P + DP_WB, 64, 0, 16 * m, i, src);
-    hpre[m] = mv16(wa, x, P[DP_BA + 16 * m + i]);
-    acc = mv16(wb, lrelu1(hpre[m]), acc);
+    hpre[m] = mv16c(wa, x, P[DP_BA + 16 * m + i]);
+    acc = mv16c(wb, lrelu1(hpre[m]), acc);
   }
   const float g0 = valid ? (acc > 0.f ? adj : 0.2f * adj) : 0.f;
 #pragma unroll 1
   for (int m = 0; m < 4; ++m) {
     W16 wbt;
     load_cols(wbt, P + DP_WB, 64, 0, 16 * m, i, src);      // (Wb chunk)^T
-    const float tt = mv16(wbt, g0, 0.f);
+    const float tt = mv16c(wbt, g0, 0.f);
     const float gh = valid ? (hpre[m] > 0.f ? tt : 0.2f * tt) : 0.f;
     const f32x4 dWb = MFMA16(g0, lrelu1(hpre[m]), zero4());   // [i][j] = sum_n g0_i lrelu(hpre_m)_j -> Wb[i][16m + j]
     const f32x4 dWa = MFMA16(gh, x, zero4());                 // [i][j] = sum_n gh_i x_j              -> Wa[16m + i][j]
