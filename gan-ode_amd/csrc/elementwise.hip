@@ -11,20 +11,31 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const gode_bn_finalize
   __shared__ double red[2][256];
   if (a.training) {
     // stats[which][column][row] (column = rep*C + c): consecutive threads read consecutive rows of one column.
-    // groups == 2: rows [0, rows0) are image group 0, [rows0, rows) group 1 -- finalised one after the other, so the
-    // running statistics see the two momentum updates in the order of the reference's two forward calls
+    // groups == 2: two BatchNorm batches in one launch.  Their partial rows are described by up to 8 segments
+    // (begin, split, end): rows [begin, split) of a segment belong to group 0, [split, end) to group 1 -- one segment with
+    // begin = 0, split = rows0, end = rows for a grouped FPROP pass (gode_igemm groups == 2), one per stride phase for a
+    // transposed-convolution stack whose rows are [first batch; second batch] (gode_igemm_stats_segments).  The groups are
+    // finalised one after the other in `order` (0: group 0 first), so the running statistics see the two momentum updates
+    // in the order of the reference's two forward calls.
     const int reps = a.ncols / a.C;
     const int ngroups = a.groups == 2 ? 2 : 1;
-    for (int grp = 0; grp < ngroups; ++grp) {
-      const int r_lo = grp == 0 ? 0 : a.rows0, r_hi = (ngroups == 2 && grp == 0) ? a.rows0 : a.rows;
-      const int nr = r_hi - r_lo;
+    for (int gi = 0; gi < ngroups; ++gi) {
+      const int grp = ngroups == 2 ? (a.order ? 1 - gi : gi) : 0;
       double s1 = 0.0, s2 = 0.0;
-      const int64_t items = (int64_t)nr * reps;
-      for (int64_t i = tid; i < items; i += 256) {
-        const int rep = (int)(i / nr); const int r = r_lo + (int)(i - (int64_t)rep * nr);
-        const int64_t o = (int64_t)(rep * a.C + c) * a.rows + r;
-        s1 += (double)a.stats[o];
-        s2 += (double)a.stats[(int64_t)a.ncols * a.rows + o];
+      const int nseg = ngroups == 2 ? (a.nseg > 0 ? a.nseg : 1) : 1;
+      for (int sg = 0; sg < nseg; ++sg) {
+        int r_lo, r_hi;
+        if (ngroups == 1) { r_lo = 0; r_hi = a.rows; }
+        else if (a.nseg > 0) { r_lo = grp == 0 ? a.seg[3 * sg] : a.seg[3 * sg + 1]; r_hi = grp == 0 ? a.seg[3 * sg + 1] : a.seg[3 * sg + 2]; }
+        else { r_lo = grp == 0 ? 0 : a.rows0; r_hi = grp == 0 ? a.rows0 : a.rows; }
+        const int nr = r_hi - r_lo;
+        const int64_t items = (int64_t)nr * reps;
+        for (int64_t i = tid; i < items; i += 256) {
+          const int rep = (int)(i / nr); const int r = r_lo + (int)(i - (int64_t)rep * nr);
+          const int64_t o = (int64_t)(rep * a.C + c) * a.rows + r;
+          s1 += (double)a.stats[o];
+          s2 += (double)a.stats[(int64_t)a.ncols * a.rows + o];
+        }
       }
       __syncthreads();
       red[0][tid] = s1; red[1][tid] = s2;
@@ -34,7 +45,7 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const gode_bn_finalize
         __syncthreads();
       }
       if (tid == 0) {
-        const double n = (double)a.count;
+        const double n = (double)((grp == 1 && a.count1 > 0) ? a.count1 : a.count);
         const double mean = red[0][0] / n;
         double var = red[1][0] / n - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -70,7 +81,10 @@ extern "C" int gode_bn_finalize(const gode_bn_finalize_op* op, void* stream) {
   if (!op || op->C <= 0 || !op->scale || !op->shift) return GODE_E_ARG;
   if (op->training) {
     if (!op->stats || !op->mean || !op->invstd || op->ncols % op->C != 0 || op->count <= 0) return GODE_E_ARG;
-    if (op->groups == 2 && (op->rows0 <= 0 || op->rows0 >= op->rows)) return GODE_E_ARG;
+    if (op->groups == 2 && op->nseg == 0 && (op->rows0 <= 0 || op->rows0 >= op->rows)) return GODE_E_ARG;
+    if (op->groups == 2 && (op->nseg < 0 || op->nseg > 8)) return GODE_E_ARG;
+    for (int i = 0; op->groups == 2 && i < op->nseg; ++i)
+      if (!(0 <= op->seg[3 * i] && op->seg[3 * i] <= op->seg[3 * i + 1] && op->seg[3 * i + 1] <= op->seg[3 * i + 2] && op->seg[3 * i + 2] <= op->rows)) return GODE_E_ARG;
   } else if (!op->running_mean || !op->running_var) return GODE_E_ARG;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(op->C), dim3(256), 0, (hipStream_t)stream, *op);
   GODE_LAUNCH_CHECK();
@@ -202,9 +216,9 @@ struct BnbGroups { int groups, rows0, rows; int64_t M0; };
 __device__ __forceinline__ BnbGroups bnb_groups(const gode_bn_bwd_op& a) {
   BnbGroups G;
   G.groups = a.groups == 2 ? 2 : 1;
-  G.M0 = G.groups == 2 ? a.M / 2 : a.M;
+  G.M0 = G.groups == 2 ? (a.M0 > 0 ? a.M0 : a.M / 2) : a.M;          // rows [0, M0): group 0, [M0, M): group 1
   G.rows0 = (int)((G.M0 + BNB_ROWS - 1) / BNB_ROWS);
-  G.rows = G.groups * G.rows0;
+  G.rows = G.groups == 2 ? G.rows0 + (int)((a.M - G.M0 + BNB_ROWS - 1) / BNB_ROWS) : G.rows0;
   return G;
 }
 
@@ -264,7 +278,7 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const gode_bn_bwd_
   if (tid == 0 && a.accumulate) { dbeta_acc = a.dbeta ? a.dbeta[c] : 0.f; dgamma_acc = a.dgamma ? a.dgamma[c] : 0.f; }
   for (int grp = 0; grp < G.groups; ++grp) {
     double s1 = 0.0, s2 = 0.0;
-    for (int r = grp * G.rows0 + tid; r < (grp + 1) * G.rows0; r += 256) {
+    for (int r = (grp == 0 ? 0 : G.rows0) + tid; r < (grp == 0 ? G.rows0 : G.rows); r += 256) {
       s1 += part[(int64_t)r * 2 * a.C + c];
       s2 += part[(int64_t)r * 2 * a.C + a.C + c];
     }
@@ -327,7 +341,7 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(float* g, const float* gin
 
 extern "C" int64_t gode_bn_bwd_work_size(int64_t M, int32_t C) {
   // (sized for the two-group form: one more chunk row, two coefficient sets)
-  const int64_t rows = (M + BNB_ROWS - 1) / BNB_ROWS + 1;
+  const int64_t rows = (M + BNB_ROWS - 1) / BNB_ROWS + 2;
   return rows * 4 * C + 6 * (int64_t)C;   // fp64 partials (2 floats each) + 3 coefficient vectors per group
 }
 
@@ -346,12 +360,13 @@ extern "C" int gode_bn_bwd(const gode_bn_bwd_op* op, void* stream) {
     return 0;
   }
   if (op->C % 4 != 0 || !op->invstd || !op->scale || !op->shift || !op->work) return GODE_E_ARG;
-  if (op->groups == 2 && (op->M % 2 != 0)) return GODE_E_ARG;
+  if (op->groups == 2 && op->M0 == 0 && (op->M % 2 != 0)) return GODE_E_ARG;
+  if (op->groups == 2 && (op->M0 < 0 || op->M0 >= op->M)) return GODE_E_ARG;
   const int C4 = op->C / 4, CL = C4 < BNB_CL ? C4 : BNB_CL;
   if (256 % CL != 0) return GODE_E_SHAPE;
   const int groups = op->groups == 2 ? 2 : 1;
-  const int64_t M0 = groups == 2 ? op->M / 2 : op->M;
-  const int rows = groups * (int)((M0 + BNB_ROWS - 1) / BNB_ROWS);
+  const int64_t M0 = groups == 2 ? (op->M0 > 0 ? op->M0 : op->M / 2) : op->M;
+  const int rows = (int)((M0 + BNB_ROWS - 1) / BNB_ROWS) + (groups == 2 ? (int)((op->M - M0 + BNB_ROWS - 1) / BNB_ROWS) : 0);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rows, (C4 + CL - 1) / CL), dim3(256), 0, st, *op);
   GODE_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(op->C), dim3(256), 0, st, *op);

@@ -1098,6 +1098,31 @@ extern "C" int gode_igemm_stats_rows0(const gode_igemm_op* op) {
   return rc ? rc : rows0;
 }
 
+extern "C" int gode_igemm_stats_segments(const gode_igemm_op* op, int32_t split_images, int32_t* seg) {
+  if (!op || !seg || op->groups == 2 || split_images <= 0 || split_images >= op->g.N) return GODE_E_ARG;
+  IgemmArgs A; int tile, mx, rows; SplitPlan sp;
+  int rc = prepare(op, &A, &tile, &mx, &rows, &sp);
+  if (rc) return rc;
+  if (sp.ksplit > 1) {
+    // split-K finish: one statistics row per SPLITK_ROWS output positions, positions in image-major order
+    const int64_t per_img = (int64_t)A.G.Xd * A.G.Xh * A.G.Xw;
+    const int64_t b = (int64_t)split_images * per_img;
+    if (b % SPLITK_ROWS != 0) return GODE_E_SHAPE;
+    seg[0] = 0; seg[1] = (int32_t)(b / SPLITK_ROWS); seg[2] = rows;
+    return 1;
+  }
+  const int bm = tile_bm(tile);
+  for (int i = 0; i < A.G.nphase; ++i) {
+    const PhaseGeom& P = A.G.ph[i];
+    const int64_t per_img = (int64_t)P.Md * P.Mh * P.Mw;       // rows of a phase are image-major
+    const int64_t b = (int64_t)split_images * per_img;
+    if (P.M != (int64_t)op->g.N * per_img) return GODE_E_SHAPE;
+    if (b % bm != 0) return GODE_E_SHAPE;                        // a tile would hold rows of both parts
+    seg[3 * i] = P.row0; seg[3 * i + 1] = P.row0 + (int32_t)(b / bm); seg[3 * i + 2] = P.row0 + gode_ceil_div(P.M, bm);
+  }
+  return A.G.nphase;
+}
+
 extern "C" int gode_igemm_stats_rows(const gode_igemm_op* op) {
   IgemmArgs A; int tile, mx, rows; SplitPlan sp;
   int rc = prepare(op, &A, &tile, &mx, &rows, &sp);

@@ -74,6 +74,11 @@ int64_t gode_igemm_work_size(const gode_igemm_op* op);
 int gode_igemm_stats_rows(const gode_igemm_op* op);
 /* rows of those that belong to image group 0 (== gode_igemm_stats_rows unless op->groups == 2) */
 int gode_igemm_stats_rows0(const gode_igemm_op* op);
+/* A stack whose batch is [first `split_images` images; the rest] with SEPARATE BatchNorm statistics per part (the generator's
+ * video and image paths decoded in one pass): which partial-statistics rows belong to which part.  Writes up to 8 segments
+ * {begin, split, end} (gode_bn_finalize_op.seg) and returns their number; GODE_E_SHAPE when a tile (or split-K statistics
+ * chunk) of this op would straddle the boundary -- the caller then runs the two parts separately. */
+int gode_igemm_stats_segments(const gode_igemm_op* op, int32_t split_images, int32_t* seg);
 /* floats needed for the packed weights of (geom, dir) */
 int64_t gode_pack_size(const gode_conv_geom* g, int dir);
 /* canonical W[co][ci][taps] -> packed panels.  co_perm (nullable, length g->Co): internal y-side channel c is
@@ -117,6 +122,11 @@ typedef struct gode_bn_finalize_op {
    * and GROUP); mean / invstd / scale / shift are [2][C] (group-major); the running statistics receive the two
    * momentum updates in group order (what two successive forward calls do), num_batches_tracked += 2. */
   int32_t groups, rows0;
+  /* groups == 2, general form (nseg > 0 overrides rows0): up to 8 row segments {begin, split, end} -- rows [begin, split) are
+   * group 0, [split, end) group 1 (gode_igemm_stats_segments: one per stride phase of a transposed-convolution stack whose
+   * rows are [first batch; second batch]); count1 (> 0): elements per channel of group 1 when the groups differ in size
+   * (count: group 0); order != 0: group 1's momentum update is applied first (the reference called that batch first). */
+  int32_t nseg, order; int64_t count1; int32_t seg[24];   /* 8 x {begin, split, end} */
 } gode_bn_finalize_op;
 int gode_bn_finalize(const gode_bn_finalize_op* op, void* stream);
 
@@ -159,6 +169,7 @@ typedef struct gode_bn_bwd_op {
    * scale / shift are [2][C] (group-major, as gode_bn_finalize writes them), the batch terms use each group's own sums,
    * dgamma / dbeta receive both groups' sums in group order (what the reference's two backward passes add up to). */
   int32_t groups, pad2_;
+  int64_t M0;   /* groups == 2: rows of group 0 (0: M / 2) */
 } gode_bn_bwd_op;
 int gode_bn_bwd(const gode_bn_bwd_op* op, void* stream);
 int64_t gode_bn_bwd_work_size(int64_t M, int32_t C);
