@@ -82,13 +82,24 @@ class ConvStack:
     per call with element strides (discriminators read the caller's video / image in place)."""
 
     def __init__(self, specs: Sequence[LayerSpec], params: Sequence[LayerParams], device, owns_input: bool,
-                 momentum=0.1, eps=1e-5, pack_cache: Optional[dict] = None, groups: int = 1):
+                 momentum=0.1, eps=1e-5, pack_cache: Optional[dict] = None, groups: int = 1, split_images: int = 0,
+                 split_order: int = 0):
         """groups == 2: ONE pass over two image groups [first source; second source] (a discriminator applied to real
         and fake in the same launches, specs built for the joint batch): every BatchNorm keeps per-group batch
         statistics -- exactly what the reference's two forward calls compute -- while the GEMMs, weight gradients and
         elementwise passes run once over twice the rows.  Conv (FPROP) stacks with caller-owned inputs only."""
         self.specs, self.params, self.device = list(specs), list(params), device
         self.groups = groups
+        # split_images > 0 (plan-owned input only): the batch is [first split_images images; the rest] -- two BatchNorm
+        # batches of DIFFERENT size decoded in one pass (the generator's video and image paths: the reference calls `main`
+        # on each, models/mocogan.py:276,293): per-part batch statistics, every GEMM / elementwise launch once over all
+        # rows.  split_order: which part the reference called first (its momentum update of the running statistics comes
+        # first).  The statistics rows of every layer must split at a tile boundary (gode_igemm_stats_segments); the
+        # constructor raises ValueError otherwise and the caller runs the two parts separately.
+        self.split, self.split_order = int(split_images), int(split_order)
+        if self.split and (groups != 1 or not owns_input or not (0 < self.split < specs[0].geom.N)):
+            raise ValueError("split ConvStack: plan-owned input, one launch group, 0 < split_images < N")
+        self._G2 = groups == 2 or self.split > 0          # two BatchNorm groups: [2][C] statistics arrays
         if groups not in (1, 2) or (groups == 2 and (owns_input or specs[0].fwd_dir != L.FPROP or specs[0].has_bn
                                                      or specs[0].geom.N % 2)):
             raise ValueError("grouped ConvStack: two groups, Conv stack, caller-owned input, no BatchNorm on layer 0")
@@ -126,8 +137,15 @@ class ConvStack:
                 self.stat_rows.append(rows)
                 self.stats.append(torch.empty(rows * 2 * ncols, **f32))
                 # per-group [groups][C] (group-major)
-                self.mean.append(torch.empty(groups * C_out, **f32)); self.invstd.append(torch.empty(groups * C_out, **f32))
-                self.scale.append(torch.empty(groups * C_out, **f32)); self.shift.append(torch.empty(groups * C_out, **f32))
+                ng = 2 if self._G2 else 1
+                self.mean.append(torch.empty(ng * C_out, **f32)); self.invstd.append(torch.empty(ng * C_out, **f32))
+                self.scale.append(torch.empty(ng * C_out, **f32)); self.shift.append(torch.empty(ng * C_out, **f32))
+                if self.split:
+                    seg = (C.c_int32 * 24)()
+                    nseg = lib.gode_igemm_stats_segments(C.byref(probe), self.split, seg)
+                    if nseg <= 0:
+                        raise ValueError(f"layer {l}: the statistics rows do not split at image {self.split} ({nseg})")
+                    self.__dict__.setdefault("_segs", {})[l] = (nseg, list(seg))
             else:
                 self.stat_rows.append(0); self.stats.append(None)
                 self.mean.append(None); self.invstd.append(None); self.scale.append(None); self.shift.append(None)
@@ -187,7 +205,7 @@ class ConvStack:
             return False
         prod, cons = self.specs[l], self.specs[l + 1]
         C_out = prod.out_dims()[4]
-        if self.groups == 2 and prod.has_bn:
+        if self._G2 and prod.has_bn:
             return True      # per-group scale/shift: consumers read the activated copy, nothing downstream knows of groups
         g = cons.geom
         taps = g.kd * g.kh * g.kw
@@ -313,20 +331,28 @@ class ConvStack:
                 patch["last"] = op
             if s.has_bn:
                 rows0 = lib.gode_igemm_stats_rows0(C.byref(op)) if G2 else 0
-                ops.append(L.BnFinalizeOp(stats=dptr(self.stats[l]), rows=self.stat_rows[l], ncols=self._ncols(s),
-                                          C=s.out_dims()[4], count=self._count(l) // self.groups, gamma=dptr(p.gamma),
-                                          beta=dptr(p.beta), running_mean=dptr(p.running_mean),
-                                          running_var=dptr(p.running_var),
-                                          num_batches_tracked=dptr(p.num_batches_tracked), mean=dptr(self.mean[l]),
-                                          invstd=dptr(self.invstd[l]), scale=dptr(self.scale[l]),
-                                          shift=dptr(self.shift[l]), momentum=self.momentum, eps=self.eps,
-                                          training=1 if training else 0, groups=self.groups if G2 else 0, rows0=rows0))
+                fin = L.BnFinalizeOp(stats=dptr(self.stats[l]), rows=self.stat_rows[l], ncols=self._ncols(s),
+                                     C=s.out_dims()[4], count=self._count(l) // self.groups, gamma=dptr(p.gamma),
+                                     beta=dptr(p.beta), running_mean=dptr(p.running_mean),
+                                     running_var=dptr(p.running_var),
+                                     num_batches_tracked=dptr(p.num_batches_tracked), mean=dptr(self.mean[l]),
+                                     invstd=dptr(self.invstd[l]), scale=dptr(self.scale[l]),
+                                     shift=dptr(self.shift[l]), momentum=self.momentum, eps=self.eps,
+                                     training=1 if training else 0, groups=self.groups if G2 else 0, rows0=rows0)
+                if self.split:
+                    per_img = self._count(l) // s.geom.N
+                    nseg, seg = self._segs[l]
+                    fin.groups, fin.nseg, fin.order = 2, nseg, self.split_order
+                    fin.count, fin.count1 = per_img * self.split, per_img * (s.geom.N - self.split)
+                    for k in range(3 * nseg):
+                        fin.seg[k] = seg[k]
+                ops.append(fin)
             if l < self.nl - 1 and self.a[l] is not None:
                 d = s.out_dims()
                 M = d[0] * d[1] * d[2] * d[3]
+                M0 = M // 2 if (G2 and s.has_bn) else ((M // d[0]) * self.split if (self.split and s.has_bn) else 0)
                 ops.append(L.BnApplyOp(y=dptr(self.y[l]), out=dptr(self.a[l]), scale=dptr(self.scale[l]),
-                                       shift=dptr(self.shift[l]), M=M, C=d[4], act=s.act,
-                                       M0=M // 2 if (G2 and s.has_bn) else 0))
+                                       shift=dptr(self.shift[l]), M=M, C=d[4], act=s.act, M0=M0))
         patch["packs"] = packs
         self._attach_work([op for op in ops if isinstance(op, L.IgemmOp)])
         return L.Program(ops), patch
@@ -453,7 +479,8 @@ class ConvStack:
                     b = L.BnBwdOp(g=dptr(self.g[l - 1]), y=dptr(self.y[l - 1]), M=M, C=Cc, act=sp.act,
                                   gamma=dptr(pp.gamma), mean=dptr(self.mean[l - 1]), invstd=dptr(self.invstd[l - 1]),
                                   scale=dptr(self.scale[l - 1]), shift=dptr(self.shift[l - 1]), accumulate=0,
-                                  eval_mode=0 if training else 1, groups=2 if self.groups == 2 else 0)
+                                  eval_mode=0 if training else 1, groups=2 if self._G2 else 0,
+                                  M0=(M // sp.out_dims()[0]) * self.split if self.split else 0)
                     # (groups == 2: per-group batch statistics ([2][C] arrays) in ONE reduce / finalize / apply triple;
                     # dgamma / dbeta receive both groups' sums in group order)
                     bn_work = max(bn_work, lib.gode_bn_bwd_work_size(M, Cc))

@@ -149,7 +149,8 @@ class _GenPlan:
     """ODE solve + decoder for `n_traj` trajectories.  full: rows = n_traj*T; select: rows = n_traj (one chosen
     time per trajectory, sample_images)."""
 
-    def __init__(self, gen: "VideoGenerator", n_traj: int, T: int, select: bool):
+    def __init__(self, gen: "VideoGenerator", n_traj: int, T: int, select: bool, zbuf=None):
+        """zbuf: latent rows of a joint pass (_GenJointPlan) -- the plan then is the latent half only (no decoder stack)."""
         dev = gen.main[0].weight.device
         self.gen, self.n, self.T, self.select, self.device = gen, n_traj, T, select, dev
         self.rows = n_traj if select else n_traj * T
@@ -165,8 +166,11 @@ class _GenPlan:
         self.traj = torch.empty(n_traj, T, 16, **f32)
         tt = torch.linspace(0, 1, T).float()            # models/mocogan_ode.py:143 -- fp32 grid built on the host
         self.dt = (tt[1:] - tt[:-1]).to(dev) if T > 1 else torch.zeros(1, **f32)
-        self.stack = ConvStack(gen._decoder_specs(self.rows), gen._decoder_params(), dev, owns_input=True,
-                               pack_cache=gen._pool.pack_cache)
+        if zbuf is None:
+            self.stack = ConvStack(gen._decoder_specs(self.rows), gen._decoder_params(), dev, owns_input=True,
+                                   pack_cache=gen._pool.pack_cache)
+        else:
+            self.stack, self._zbuf = None, zbuf
         self.ode_work = torch.empty(L.lib().gode_ode_bwd_work_size(n_traj), **f32)
         self._ode_ptrs = None
         self.busy = False
@@ -314,36 +318,137 @@ class _GenPlan:
         if arena is not None:
             _, _, gz = self.stack.backward(gout, need_input_grad=True, into=self._decoder_into(arena))
             self._decoder_pass_done()
+            self.latent_backward(gz.data_ptr(), arena, gz)
+            self.busy = False
+            return None, None
+        flat, views, gz = self.stack.backward(gout, need_input_grad=True)
+        motion = self.latent_backward(gz.data_ptr(), None, gz)
+        self.busy = False
+        return views, motion
+
+    def latent_backward(self, gz_ptr, arena, keep):
+        """Adjoint of the latent half given the gradient wrt its latent rows (gz_ptr: first row, Z_COLS floats per row).
+        arena: gradients go straight into the trainer's arena (first writer of a step stores, later ones add) and the
+        launch may be deferred into the trainer's batch; else -> list of gradient tensors (pre-net + ODEFunc order)."""
+        self.bwd_op.gz = gz_ptr
+        if arena is not None:
             ode = [q for q in self._ode_params() if q is not None]
             tgt = [arena.target(q) for q in ode]
             base, acc = tgt[0]
             off = base.data_ptr() - (0 if self._ode_ptrs[0] is not None else 2128 * 4)   # kernel offsets start at Wa
-            self.bwd_op.gz = gz.data_ptr()
             self.bwd_op.grads = off
             self.bwd_op.accumulate = 1 if acc else 0
             batch = getattr(self.gen, "_adjoint_batch", None)
             if batch is not None and self.gen.ode_method == "dopri5" and self.gen.adjoint_substeps == 0:
-                # adaptive adjoints of the video and the image path: one launch (see _RnnGenPlan.backward)
+                # adaptive adjoints of the video and the image path: one launch (see _RnnGenPlan.latent_backward)
                 batch["ops"].append(self.bwd_op)
-                batch["keep"].append(gz)
+                batch["keep"].append(keep)
                 if len(batch["ops"]) >= batch["expect"]:
                     self.gen.flush_adjoints()
             else:
                 L.run_one(self.bwd_op, stream_ptr())
-            self.busy = False
-            return None, None
-        flat, views, gz = self.stack.backward(gout, need_input_grad=True)
+            return None
         grads = torch.empty(L.ODE_NPARAM, dtype=torch.float32, device=self.device)
-        self.bwd_op.gz = gz.data_ptr()
         self.bwd_op.grads = grads.data_ptr()
         self.bwd_op.accumulate = 0
         L.run_one(self.bwd_op, stream_ptr())
-        self.busy = False
         offs = [(0, 1024, (64, 16)), (1024, 64, (64,)), (1088, 1024, (16, 64)), (2112, 16, (16,)),
                 (2128, 256, (16, 16)), (2384, 16, (16,)), (2400, 256, (16, 16)), (2656, 16, (16,))]
         if self._ode_ptrs[0] is None:
             offs = offs[4:]
-        return views, [grads[o:o + n].view(shp) for o, n, shp in offs]
+        return [grads[o:o + n].view(shp) for o, n, shp in offs]
+
+
+class _GenJointPlan:
+    """sample_videos(nv) and sample_images(ni) of one generator step decoded in ONE pass: latent rows [nv*T video rows | ni
+    image rows], two BatchNorm batches (ConvStack(split_images=nv*T)): the reference calls `main` on the 512-row and on
+    the 32-row batch separately (models/mocogan.py:276,293) -- same arithmetic per element, but the image path's GEMMs
+    (M = 32 rows: 45-65 TFLOP/s on their own) ride along in the video path's launches and every elementwise / reduction
+    launch is issued once.  `vid` / `img`: the latent halves (plans without a decoder) writing into the joint buffer.
+    images_first: the reference called sample_images first (the discriminator steps), so its BatchNorm momentum update
+    comes first."""
+
+    def __init__(self, gen, nv, ni, T, images_first):
+        dev = gen.main[0].weight.device
+        self.gen, self.nv, self.ni, self.T, self.device = gen, nv, ni, T, dev
+        self.rows_v, self.rows_i = nv * T, ni
+        self.stack = ConvStack(gen._decoder_specs(self.rows_v + self.rows_i), gen._decoder_params(), dev, owns_input=True,
+                               pack_cache=gen._pool.pack_cache, split_images=self.rows_v, split_order=1 if images_first else 0)
+        self.vid = gen._plan_cls(gen, nv, T, False, zbuf=self.stack.x_in[:self.rows_v])
+        self.img = gen._plan_cls(gen, ni, T, True, zbuf=self.stack.x_in[self.rows_v:])
+        self.images_first = images_first
+        self.busy = False
+        self._latent_ev = None
+
+    def subplans(self):
+        """in the order of the reference's calls (= the order of the host draws)"""
+        return (self.img, self.vid) if self.images_first else (self.vid, self.img)
+
+    def forward(self, host, training, keep):
+        """host: [(x, content, sel) per sub-plan in call order], or None when the latents were prefetched."""
+        if host is None:
+            torch.cuda.current_stream().wait_event(self._latent_ev)
+        else:
+            subs = self.subplans()
+            for sub, h in zip(subs, host):
+                sub.stage_inputs(*h)
+            self.gen._launch_latents(list(subs))
+        out = self.stack.forward(training)
+        self.busy = keep
+        return out
+
+    def backward(self, g_joint, arena):
+        subs = (self.vid, self.img)
+        offs = (0, 4 * self.rows_v * Z_COLS)
+        if arena is not None:
+            _, _, gz = self.stack.backward(g_joint, need_input_grad=True, into=self.vid._decoder_into(arena))
+            self.vid._decoder_pass_done()
+            for sub, off in zip(subs, offs):
+                sub.latent_backward(gz.data_ptr() + off, arena, gz)
+            self.busy = False
+            return None, None
+        flat, views, gz = self.stack.backward(g_joint, need_input_grad=True)
+        motion = None
+        for sub, off in zip(subs, offs):
+            m = sub.latent_backward(gz.data_ptr() + off, None, gz)
+            motion = m if motion is None else [a + b for a, b in zip(motion, m)]
+        self.busy = False
+        return views, motion
+
+
+class _GenJointFn(torch.autograd.Function):
+    """The joint generator pass as one autograd node with two outputs (video frames, image frames)."""
+
+    @staticmethod
+    def forward(ctx, plan, host, training, keep, n_dec, *params):
+        out = plan.forward(host, training, keep)
+        ctx.plan, ctx.n_dec, ctx.n_params = plan, n_dec, len(params)
+        ctx.lease = _Lease(plan)
+        ctx.out_shape = tuple(out.shape)
+        return out.narrow(0, 0, plan.rows_v), out.narrow(0, plan.rows_v, plan.rows_i)
+
+    @staticmethod
+    def backward(ctx, gv, gi):
+        plan = ctx.plan
+        ctx.lease.check(type(plan.gen).__name__ + " (joint pass)")
+        g = torch.empty(ctx.out_shape, dtype=torch.float32, device=plan.device)
+        for part, gg in ((g.narrow(0, 0, plan.rows_v), gv), (g.narrow(0, plan.rows_v, plan.rows_i), gi)):
+            if gg is None:
+                part.zero_()
+            else:
+                part.copy_(gg)
+        arena = getattr(plan.gen, "_gode_arena", None)
+        if arena is not None and arena.active:
+            plan.backward(g, arena)
+            return (None,) * (5 + ctx.n_params)
+        views, motion = plan.backward(g, None)
+        grads = []
+        for wv, gvw, bv in views:
+            grads.append(wv)
+            if gvw is not None:
+                grads += [gvw, bv]
+        assert len(grads) == ctx.n_dec and len(motion) == ctx.n_params - ctx.n_dec
+        return (None, None, None, None, None, *grads, *motion)
 
 
 class _GenFn(torch.autograd.Function):
@@ -602,7 +707,7 @@ class VideoGenerator(nn.Module):
             raise RuntimeError("prefetch_latents: the previous prefetch has not been consumed "
                                f"({len(self._prefetched)} calls left)")
         for kind, n in calls:
-            if kind not in ("videos", "images"):
+            if kind not in ("videos", "images", "pair_vi", "pair_iv"):
                 raise ValueError(f"prefetch_latents: unknown call kind {kind!r}")
         main = torch.cuda.current_stream()
         lat = self.__dict__.get("_latent_stream")
@@ -617,6 +722,14 @@ class VideoGenerator(nn.Module):
             raise RuntimeError(f"prefetch_latents: more than {_Pool.MAX_PLANS} calls of one shape ahead (each holds its own "
                                "plan and buffers); announce fewer calls at a time")
         for kind, n in calls:                  # (plans are created on the caller's stream, like every other plan)
+            if kind.startswith("pair"):        # n = (n_videos, n_images): sample_pair -- one joint plan, two latent halves
+                plan = self._joint_plan(n[0], n[1], T, kind == "pair_iv")
+                if plan is None:
+                    raise RuntimeError(f"prefetch_latents: {kind}{n} cannot be decoded jointly; announce the two calls")
+                plan.busy = True
+                plans.append(plan)
+                queue.append((kind, n, T, plan))
+                continue
             select = kind == "images"
             plan = self._pool.get((n, T, select), lambda: self._plan_cls(self, n, T, select))
             plan.busy = True                   # reserved: a second call of the same shape gets its own plan and buffers
@@ -624,10 +737,13 @@ class VideoGenerator(nn.Module):
             queue.append((select, n, T, plan))
         lat.wait_stream(main)                  # weights written on the caller's stream (Adam) are complete
         with torch.cuda.stream(lat):
+            latent_plans = []
             for plan, (select, n, _, _) in zip(plans, queue):
                 # draw and stage call by call: a generator may hand out a reused host buffer (the ODE-RNN noise stack)
-                plan.stage_inputs(*self._host_inputs(select, n, T))
-            self._launch_latents(plans)
+                for sub in (plan.subplans() if isinstance(plan, _GenJointPlan) else (plan,)):
+                    sub.stage_inputs(*self._host_inputs(sub.select, sub.n, T))
+                    latent_plans.append(sub)
+            self._launch_latents(latent_plans)
             ev = torch.cuda.Event()
             ev.record(lat)
         for p in plans:
@@ -670,8 +786,8 @@ class VideoGenerator(nn.Module):
             return None
         s0, n0, T0, plan = q[0]
         if (s0, n0, T0) != (select, n, T):
-            raise RuntimeError(f"prefetch_latents promised {'sample_images' if s0 else 'sample_videos'}({n0}) next, got "
-                               f"{'sample_images' if select else 'sample_videos'}({n}, video_len={T})")
+            name = lambda k: k if isinstance(k, str) else ("sample_images" if k else "sample_videos")      # noqa: E731
+            raise RuntimeError(f"prefetch_latents promised {name(s0)}({n0}) next, got {name(select)}({n}, video_len={T})")
         q.pop(0)
         return plan
 
@@ -734,6 +850,44 @@ class VideoGenerator(nn.Module):
             x, content, sel = self._host_inputs(True, num_samples, T)
             h = self._run(num_samples, T, True, x, content, sel)
         return h.view(num_samples, h.size(2), h.size(3), self.n_channels).permute(0, 3, 1, 2), None
+
+    def sample_pair(self, n_videos, n_images, images_first=False):
+        """(sample_videos(n_videos), sample_images(n_images)) -- or, images_first, the same two calls in the other order --
+        with the host draws of those two calls in that order, decoded in ONE pass over [video rows | image rows] with
+        per-call BatchNorm batch statistics (_GenJointPlan): -> ((videos, labels), (images, None)).  Falls back to the two
+        calls when the layers' statistics rows do not split at the batch boundary (unusual batch sizes)."""
+        T = self.video_length
+        _require_gpu(self.main[0].weight, type(self).__name__)
+        plan = self._take_prefetched("pair_iv" if images_first else "pair_vi", (n_videos, n_images), T)
+        host = None
+        if plan is None:
+            plan = self._joint_plan(n_videos, n_images, T, images_first)
+            if plan is None:
+                if images_first:
+                    im = self.sample_images(n_images)
+                    return self.sample_videos(n_videos), im
+                vd = self.sample_videos(n_videos)
+                return vd, self.sample_images(n_images)
+            host = [self._host_inputs(sub.select, sub.n, T) for sub in plan.subplans()]
+        dec, ode = self._param_list()
+        keep = torch.is_grad_enabled() and any(p.requires_grad for p in dec + ode)
+        hv, hi = _GenJointFn.apply(plan, host, self.training, keep, len(dec), *dec, *ode)
+        H, W = hv.size(2), hv.size(3)
+        vid = hv.view(n_videos, T, H, W, self.n_channels).permute(0, 4, 1, 2, 3)
+        img = hi.view(n_images, H, W, self.n_channels).permute(0, 3, 1, 2)
+        return (vid, self._zero_labels(n_videos, vid.device)), (img, None)
+
+    def _joint_plan(self, nv, ni, T, images_first):
+        """A free joint plan for this shape, or None when the shape cannot be decoded jointly."""
+        key = ("pair", nv, ni, T, images_first)
+        bad = self.__dict__.setdefault("_no_joint", set())
+        if key in bad:
+            return None
+        try:
+            return self._pool.get(key, lambda: _GenJointPlan(self, nv, ni, T, images_first))
+        except ValueError:
+            bad.add(key)
+            return None
 
     def sample_z_content(self, num_samples, video_len=None):
         """models/mocogan.py:249-257 -> [N*T, 50], the same code on all T rows of a video."""
@@ -798,8 +952,8 @@ class VideoGeneratorMNISTODE(VideoGeneratorMNIST):
 class _RnnGenPlan(_GenPlan):
     """ODE-RNN latent (gode_odernn_fwd/bwd) + decoder.  x_host carries the noise stack [T+1, n, 16]."""
 
-    def __init__(self, gen, n_traj, T, select):
-        super().__init__(gen, n_traj, T, select)
+    def __init__(self, gen, n_traj, T, select, zbuf=None):
+        super().__init__(gen, n_traj, T, select, zbuf=zbuf)
         f32 = dict(dtype=torch.float32, device=self.device)
         self.noise = self.x        # [T+1, n, 16]: h_0 and the per-frame GRU inputs (staged by the base class)
         self.hp = torch.empty(n_traj, T, 16, **f32)
@@ -826,7 +980,8 @@ class _RnnGenPlan(_GenPlan):
             self._ode_ptrs = ptrs
             op = L.OdeRnnParams(*ptrs)
             self.fwd_op = L.OdeRnnFwdOp(p=op, noise=dptr(self.noise), content=dptr(self.content), sel_t=dptr(self.sel),
-                                        z=dptr(self.stack.x_in), hs=None, hp=dptr(self.hp), nsteps=dptr(self.nsteps),
+                                        z=dptr(self.stack.x_in if self.stack is not None else self._zbuf), hs=None,
+                                        hp=dptr(self.hp), nsteps=dptr(self.nsteps),
                                         N=self.n, T=self.T, rtol=self.gen.ode_rtol, atol=self.gen.ode_atol, zcols=Z_COLS,
                                         sync=dptr(self.sync_f))
             self.bwd_op = L.OdeRnnBwdOp(p=op, noise=dptr(self.noise), hp=dptr(self.hp), sel_t=dptr(self.sel), gz=None,
@@ -839,15 +994,13 @@ class _RnnGenPlan(_GenPlan):
         self.bwd_op.rtol, self.bwd_op.atol = self.gen.ode_rtol, self.gen.ode_atol
         self.bwd_op.substeps = self.gen.adjoint_substeps
 
-    def backward(self, gout, arena=None):
+    def latent_backward(self, gz_ptr, arena, keep):
+        self.bwd_op.gz = gz_ptr
         if arena is not None:
-            # decoder gradients and the 2176 ODEFunc + GRU gradients go straight into the trainer's arena: the eight
-            # tensors are its tail, contiguous in the kernel's output order (VideoGeneratorMNISTODERNN._arena_tail)
-            _, _, gz = self.stack.backward(gout, need_input_grad=True, into=self._decoder_into(arena))
-            self._decoder_pass_done()
+            # the 2176 ODEFunc + GRU gradients go straight into the trainer's arena: the eight tensors are its tail,
+            # contiguous in the kernel's output order (VideoGeneratorMNISTODERNN._arena_tail)
             tgt = [arena.target(q) for q in self._rnn_params()]
             base, acc = tgt[0]
-            self.bwd_op.gz = gz.data_ptr()
             self.bwd_op.grads = base.data_ptr()
             self.bwd_op.accumulate = 1 if acc else 0
             batch = getattr(self.gen, "_adjoint_batch", None)
@@ -855,21 +1008,17 @@ class _RnnGenPlan(_GenPlan):
                 # the trainer announced how many generator passes this backward holds (video + image path of the G step):
                 # their adjoints -- one workgroup each -- go out as ONE launch once the last decoder backward is through
                 batch["ops"].append(self.bwd_op)
-                batch["keep"].append(gz)
+                batch["keep"].append(keep)
                 if len(batch["ops"]) >= batch["expect"]:
                     self.gen.flush_adjoints()
             else:
                 L.run_one(self.bwd_op, stream_ptr())
-            self.busy = False
-            return None, None
-        flat, views, gz = self.stack.backward(gout, need_input_grad=True)
+            return None
         grads = torch.empty(L.ODERNN_NPARAM, dtype=torch.float32, device=self.device)
-        self.bwd_op.gz = gz.data_ptr()
         self.bwd_op.grads = grads.data_ptr()
         self.bwd_op.accumulate = 0
         L.run_one(self.bwd_op, stream_ptr())
-        self.busy = False
-        return views, [grads[o:o + n].view(shp) for o, n, shp in _RNN_GRAD_OFFS]
+        return [grads[o:o + n].view(shp) for o, n, shp in _RNN_GRAD_OFFS]
 
 
 _RNN_GRAD_OFFS = [(0, 256, (16, 16)), (256, 16, (16,)), (272, 256, (16, 16)), (528, 16, (16,)),

@@ -435,3 +435,50 @@ def test_trainer_with_paired_passes_matches_the_two_pass_schedule():
     assert np.allclose(runs[0][0][1], runs[1][0][1], rtol=1e-3, atol=0), runs          # after Adam steps: sign-like updates
     for k in runs[0][1]:
         assert rel_err(runs[0][1][k].cpu().double(), runs[1][1][k].cpu().double()) < 5e-3, k
+
+
+@pytest.mark.parametrize("kind", ["mnist", "odernn", "ucf"])
+@pytest.mark.parametrize("images_first", [False, True])
+def test_joint_generator_pass_equals_the_two_calls(kind, images_first):
+    """VideoGenerator.sample_pair: sample_videos(B) and sample_images(B) decoded in ONE pass over [B*T video rows | B image
+    rows] with two BatchNorm batches of unequal size.  Same draws, same per-call batch statistics, same running-stat
+    update order as the two calls of the reference (models/mocogan.py:271-295); only the summation order of the weight
+    gradients (one pass over 17 row blocks instead of 16 + 1) differs."""
+    def make():
+        seed_all(71)
+        if kind == "ucf":
+            gen = G.VideoGenerator(3, 50, 0, 16, 16, dim_hidden=16, ngf=8)
+        elif kind == "odernn":
+            gen = G.VideoGeneratorMNISTODERNN(1, 50, 0, 16, 16, ngf=16)
+        else:
+            gen = G.VideoGeneratorMNISTODE(1, 50, 0, 16, 16, ngf=16)
+        return gen.cuda()
+    B = 4
+    res = []
+    for joint in (False, True):
+        gen = make()
+        seed_all(72)
+        if joint:
+            (vid, lab), (img, none) = gen.sample_pair(B, B, images_first=images_first)
+            assert none is None and lab.dtype == torch.float64 and lab.shape == (B,)
+        elif images_first:
+            img, _ = gen.sample_images(B)
+            vid, _ = gen.sample_videos(B)
+        else:
+            vid, _ = gen.sample_videos(B)
+            img, _ = gen.sample_images(B)
+        wv = torch.linspace(-1, 1, vid.numel(), device="cuda").view(vid.shape)
+        wi = torch.linspace(1, -1, img.numel(), device="cuda").view(img.shape)
+        loss = (vid * wv).sum() + 3.0 * (img * wi).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((vid.detach().clone(), img.detach().clone(), [p.grad.clone() for p in gen.parameters() if p.grad is not None],
+                    [b.clone() for b in gen.buffers()], [n for n, p in gen.named_parameters() if p.grad is not None]))
+    (v0, i0, g0, b0, names), (v1, i1, g1, b1, _) = res
+    assert v0.shape == v1.shape and i0.shape == i1.shape and len(g0) == len(g1) > 8
+    assert float((v0 - v1).abs().max()) <= 1e-5 and float((i0 - i1).abs().max()) <= 1e-5    # (other tile shapes: fp32 rounding)
+    for a, b in zip(b0, b1):            # running mean / var: both updates, in the reference's call order
+        assert float((a.double() - b.double()).abs().max()) <= 1e-6 * (1 + float(a.abs().max()))
+    for n, a, b in zip(names, g0, g1):
+        scale = float(a.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 1e-3 * scale, (n, float((a - b).abs().max()), scale)   # (4-sample BN batches)
