@@ -877,6 +877,13 @@ class VideoGenerator(nn.Module):
         img = hi.view(n_images, H, W, self.n_channels).permute(0, 3, 1, 2)
         return (vid, self._zero_labels(n_videos, vid.device)), (img, None)
 
+    def can_pair(self, n_videos, n_images, images_first=False):
+        """Can sample_pair decode these two batches in one pass?  (Builds the plan on first use.)"""
+        key = ("pair", n_videos, n_images, self.video_length, images_first)
+        if key in self.__dict__.get("_no_joint", ()):
+            return False
+        return bool(self._pool.plans.get(key)) or self._joint_plan(n_videos, n_images, self.video_length, images_first) is not None
+
     def _joint_plan(self, nv, ni, T, images_first):
         """A free joint plan for this shape, or None when the shape cannot be decoded jointly."""
         key = ("pair", nv, ni, T, images_first)

@@ -456,7 +456,8 @@ class GanTrainer:
 
     def __init__(self, gen, dis_vid, dis_img, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5, d_iters=2,
                  process_group=None, freeze_d_in_g_step=True, freeze_gc=False, direct_grads=True, sync_replicas=True,
-                 overlap_image_d=True, graph=False, pair_d_passes=True, prefetch_latents=True, overlap_allreduce=True):
+                 overlap_image_d=True, graph=False, pair_d_passes=True, prefetch_latents=True, overlap_allreduce=True,
+                 joint_generator_passes=True):
         self.gen, self.dis_vid, self.dis_img = gen, dis_vid, dis_img
         mk = lambda m: FusedAdam(m.parameters(), lr=lr, betas=betas, weight_decay=weight_decay)  # noqa: E731
         self.gen_opt, self.vid_opt, self.img_opt = mk(gen), mk(dis_vid), mk(dis_img)
@@ -479,6 +480,11 @@ class GanTrainer:
         # a side stream.  Bit-identical results; what it buys is the ODE-RNN generator's six one-workgroup solves per
         # iteration running side by side in one launch, and the two adjoints of the G step likewise (flush_adjoints).
         self.prefetch = bool(prefetch_latents)
+        # joint_generator_passes: the two generator calls between two generator updates (sample_images + sample_videos of
+        # an inner discriminator pass; sample_videos + sample_images of the G step) are decoded in one pass over both
+        # batches with per-call BatchNorm statistics (VideoGenerator.sample_pair)
+        self.joint_g = bool(joint_generator_passes)
+        self._paired_fake_vid = None
         # overlap_allreduce (world > 1): every all-reduce is issued asynchronously (the process group's own stream) and the
         # optimiser step that consumes it is DEFERRED to the point where that network is next needed -- a discriminator's
         # all-reduce then runs under the next no-grad generator forward, and the generator's arena goes out in two parts:
@@ -630,8 +636,10 @@ class GanTrainer:
             return losses[0]
         return torch.stack(losses).mean()
 
-    def d_image_step(self, real_img, _join=True, _defer=False):
-        """mnist_moco_ode.py:115-131.  real_img: [B,C,H,W], or a list of such shards (virtual replicas)."""
+    def d_image_step(self, real_img, _join=True, _defer=False, _pair_videos=0):
+        """mnist_moco_ode.py:115-131.  real_img: [B,C,H,W], or a list of such shards (virtual replicas).
+        _pair_videos (step() only): the batch size of the d_video_step that follows -- its fake videos are generated here,
+        in the same decoder pass as this step's fake images (VideoGenerator.sample_pair), and kept for it."""
         shards = _shards(real_img)
         side = self._side
         main = torch.cuda.current_stream() if side is not None else None
@@ -647,8 +655,11 @@ class GanTrainer:
             if not self.pair_d:
                 with on_side():
                     pr, _ = self.dis_img(x)
-            with torch.no_grad():
-                fake, _ = self.gen.sample_images(B)      # generator work stays on the caller's stream
+            with torch.no_grad():                        # generator work stays on the caller's stream
+                if _pair_videos:
+                    self._paired_fake_vid, (fake, _) = self.gen.sample_pair(_pair_videos, B, images_first=True)
+                else:
+                    fake, _ = self.gen.sample_images(B)
             if side is not None:
                 ev = torch.cuda.Event()
                 ev.record(main)
@@ -691,7 +702,12 @@ class GanTrainer:
             if not self.pair_d:
                 pr, _ = self.dis_vid(real)
             with torch.no_grad():
-                fake, _ = self.gen.sample_videos(B)
+                fake, self._paired_fake_vid = self._paired_fake_vid, None
+                if fake is not None:                     # generated by the d_image_step before (see _pair_videos)
+                    fake = fake[0]
+                    assert fake.shape[0] == B
+                else:
+                    fake, _ = self.gen.sample_videos(B)
             if not begun:
                 # (paired pass) the generator forward above does not read this discriminator: its previous step's
                 # all-reduce -- deferred, see overlap_allreduce -- has been running under it; now wait, update, begin
@@ -709,6 +725,10 @@ class GanTrainer:
             self._flush(self.dis_vid)
         return self._mean(losses)
 
+    def _can_pair(self, n_videos, n_images, images_first):
+        return self.joint_g and hasattr(self.gen, "can_pair") and next(self.gen.parameters()).is_cuda and \
+            self.gen.can_pair(n_videos, n_images, images_first)
+
     def g_step(self, B, shards=1):
         """mnist_moco_ode.py:153-163; `shards` virtual replicas of batch B each."""
         self._begin(self.gen, self.gen_opt)
@@ -725,9 +745,13 @@ class GanTrainer:
         batch_adj = self.prefetch and id(self.gen) in self.arenas and hasattr(self.gen, "flush_adjoints")
         early_ar = self.world > 1 and self.overlap_ar and id(self.gen) in self.arenas
         try:
+            joint = shards == 1 and self._can_pair(B, B, False)
             for _ in range(shards):
-                fake_vid, _ = self.gen.sample_videos(B)
-                fake_img, _ = self.gen.sample_images(B)
+                if joint:          # both calls' rows in one decoder pass (two BatchNorm batches)
+                    (fake_vid, _), (fake_img, _) = self.gen.sample_pair(B, B)
+                else:
+                    fake_vid, _ = self.gen.sample_videos(B)
+                    fake_img, _ = self.gen.sample_images(B)
                 pv, _ = self.dis_vid(fake_vid)
                 pi, _ = self.dis_img(fake_img)
                 loss = bce_with_logits_pair(pv, 1.0, pi, 1.0)
@@ -736,7 +760,7 @@ class GanTrainer:
                 if early_ar and shards == 1:
                     # both generator passes' decoder backward queued -> the decoder block of the arena is complete: its
                     # all-reduce goes out now, under the latent adjoint(s)
-                    self.gen._decoder_passes_left = 2
+                    self.gen._decoder_passes_left = 1 if joint else 2
                     self.gen._on_decoder_grads = self._early_decoder_allreduce
                 loss.backward(gradient=unit_grad(loss.device))
                 self.gen._on_decoder_grads = None
@@ -767,17 +791,28 @@ class GanTrainer:
         B, nsh = first[0].shape[0], len(first)
         li = lv = None
         # (virtual replicas -- lists of shards, a parity-testing device -- repeat every call per shard: call by call there)
+        # joint generator passes: the fake images of d_image_step i and the fake videos of d_video_step i come out of one
+        # decoder pass (no generator update lies between the two calls), like the G step's two batches
+        pair = [0] * self.d_iters
+        if nsh == 1:
+            for i in range(self.d_iters):
+                nv, ni = _shards(real_vids[i])[0].shape[0], _shards(real_imgs[i])[0].shape[0]
+                if len(_shards(real_vids[i])) == 1 and self._can_pair(nv, ni, True):
+                    pair[i] = nv
         if self.prefetch and nsh == 1 and hasattr(self.gen, "prefetch_latents") and next(self.gen.parameters()).is_cuda:
             calls = []
             for i in range(self.d_iters):
+                if pair[i]:
+                    calls.append(("pair_iv", (pair[i], _shards(real_imgs[i])[0].shape[0])))
+                    continue
                 calls += [("images", x.shape[0]) for x in _shards(real_imgs[i])]
                 calls += [("videos", x.shape[0]) for x in _shards(real_vids[i])]
-            calls += [("videos", B), ("images", B)] * nsh
+            calls += [("pair_vi", (B, B))] if self._can_pair(B, B, False) else [("videos", B), ("images", B)]
             self.gen.prefetch_latents(calls)
         try:
             for i in range(self.d_iters):
                 # (inside step() the discriminators' optimiser steps are deferred: see overlap_allreduce)
-                li = self.d_image_step(real_imgs[i], _join=False, _defer=True)     # side stream (see overlap_image_d)
+                li = self.d_image_step(real_imgs[i], _join=False, _defer=True, _pair_videos=pair[i])    # side stream
                 lv = self.d_video_step(real_vids[i], _defer=True)
             if self._pending:
                 # the G step reads both discriminators: their deferred updates land now (the image discriminator's on its
@@ -791,6 +826,7 @@ class GanTrainer:
             self._join_side()                                         # the G step reads the updated image discriminator
             lg = self.g_step(B, nsh)
         except BaseException:
+            self._paired_fake_vid = None
             if hasattr(self.gen, "discard_prefetched"):
                 self.gen.discard_prefetched()
             raise
