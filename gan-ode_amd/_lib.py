@@ -45,7 +45,7 @@ class BnFinalizeOp(C.Structure):
                 ("beta", ptr), ("running_mean", ptr), ("running_var", ptr), ("num_batches_tracked", ptr),
                 ("mean", ptr), ("invstd", ptr), ("scale", ptr), ("shift", ptr), ("momentum", f32), ("eps", f32),
                 ("training", i32), ("pad_", i32), ("groups", i32), ("rows0", i32), ("nseg", i32), ("order", i32),
-                ("count1", i64), ("seg", i32 * 24)]
+                ("count1", i64), ("seg", i32 * 24), ("stats1", ptr), ("rows1", i32), ("pad3_", i32)]
     KIND = OP_BN_FINALIZE
 
 
@@ -126,7 +126,7 @@ _STRUCTS = {0: ConvGeom, OP_IGEMM: IgemmOp, OP_WGRAD: WgradOp, OP_BN_FINALIZE: B
             OP_ODE_FWD: OdeFwdOp, OP_ODE_BWD: OdeBwdOp, OP_BCE: BceOp, OP_ADAM: AdamOp, OP_PACK: PackOp,
             OP_ODERNN_FWD: OdeRnnFwdOp, OP_ODERNN_BWD: OdeRnnBwdOp, OP_BN_APPLY: BnApplyOp, OP_COL2IM: Col2imOp}
 
-EXPORTS = ["gode_igemm", "gode_igemm_stats_rows", "gode_igemm_stats_rows0", "gode_igemm_stats_segments", "gode_igemm_work_size", "gode_pack_size", "gode_pack_weights", "gode_wgrad",
+EXPORTS = ["gode_igemm", "gode_igemm_stats_rows", "gode_igemm_stats_rows0", "gode_igemm_stats_segments", "gode_igemm_model_cycles", "gode_igemm_work_size", "gode_pack_size", "gode_pack_weights", "gode_wgrad",
            "gode_wgrad_work_size", "gode_wgrad_auto_splits", "gode_bn_finalize", "gode_bn_bwd",
            "gode_bn_bwd_work_size", "gode_bn_apply", "gode_col2im", "gode_ode_fwd", "gode_ode_bwd", "gode_ode_fwd_multi", "gode_ode_bwd_multi", "gode_ode_bwd_work_size", "gode_odernn_fwd",
            "gode_odernn_bwd", "gode_odernn_bwd_work_size", "gode_odernn_sync_size", "gode_odernn_fwd_multi",
@@ -159,6 +159,8 @@ def lib():
     L.gode_igemm_stats_rows.argtypes = [ptr]
     L.gode_igemm_stats_rows0.argtypes = [ptr]
     L.gode_igemm_stats_segments.argtypes = [ptr, i32, ptr]
+    L.gode_igemm_model_cycles.argtypes = [ptr]
+    L.gode_igemm_model_cycles.restype = C.c_double
     L.gode_igemm_work_size.argtypes = [ptr]
     L.gode_igemm_work_size.restype = i64
     L.gode_pack_size.argtypes = [ptr, C.c_int]

@@ -22,19 +22,22 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const gode_bn_finalize
     for (int gi = 0; gi < ngroups; ++gi) {
       const int grp = ngroups == 2 ? (a.order ? 1 - gi : gi) : 0;
       double s1 = 0.0, s2 = 0.0;
-      const int nseg = ngroups == 2 ? (a.nseg > 0 ? a.nseg : 1) : 1;
+      const int nseg = (ngroups == 2 && !a.stats1) ? (a.nseg > 0 ? a.nseg : 1) : 1;
       for (int sg = 0; sg < nseg; ++sg) {
         int r_lo, r_hi;
-        if (ngroups == 1) { r_lo = 0; r_hi = a.rows; }
+        if (ngroups == 1 || a.stats1) { r_lo = 0; r_hi = (grp == 1 && a.stats1) ? a.rows1 : a.rows; }
         else if (a.nseg > 0) { r_lo = grp == 0 ? a.seg[3 * sg] : a.seg[3 * sg + 1]; r_hi = grp == 0 ? a.seg[3 * sg + 1] : a.seg[3 * sg + 2]; }
         else { r_lo = grp == 0 ? 0 : a.rows0; r_hi = grp == 0 ? a.rows0 : a.rows; }
+        // (stats1: the second group's partial sums are an array of their own, written by a launch of its own)
+        const float* st = (grp == 1 && a.stats1) ? a.stats1 : a.stats;
+        const int stride = (grp == 1 && a.stats1) ? a.rows1 : a.rows;
         const int nr = r_hi - r_lo;
         const int64_t items = (int64_t)nr * reps;
         for (int64_t i = tid; i < items; i += 256) {
           const int rep = (int)(i / nr); const int r = r_lo + (int)(i - (int64_t)rep * nr);
-          const int64_t o = (int64_t)(rep * a.C + c) * a.rows + r;
-          s1 += (double)a.stats[o];
-          s2 += (double)a.stats[(int64_t)a.ncols * a.rows + o];
+          const int64_t o = (int64_t)(rep * a.C + c) * stride + r;
+          s1 += (double)st[o];
+          s2 += (double)st[(int64_t)a.ncols * stride + o];
         }
       }
       __syncthreads();
@@ -81,7 +84,8 @@ extern "C" int gode_bn_finalize(const gode_bn_finalize_op* op, void* stream) {
   if (!op || op->C <= 0 || !op->scale || !op->shift) return GODE_E_ARG;
   if (op->training) {
     if (!op->stats || !op->mean || !op->invstd || op->ncols % op->C != 0 || op->count <= 0) return GODE_E_ARG;
-    if (op->groups == 2 && op->nseg == 0 && (op->rows0 <= 0 || op->rows0 >= op->rows)) return GODE_E_ARG;
+    if (op->stats1 && (op->groups != 2 || op->rows1 <= 0 || op->rows <= 0)) return GODE_E_ARG;
+    if (op->groups == 2 && !op->stats1 && op->nseg == 0 && (op->rows0 <= 0 || op->rows0 >= op->rows)) return GODE_E_ARG;
     if (op->groups == 2 && (op->nseg < 0 || op->nseg > 8)) return GODE_E_ARG;
     for (int i = 0; op->groups == 2 && i < op->nseg; ++i)
       if (!(0 <= op->seg[3 * i] && op->seg[3 * i] <= op->seg[3 * i + 1] && op->seg[3 * i + 1] <= op->seg[3 * i + 2] && op->seg[3 * i + 2] <= op->rows)) return GODE_E_ARG;

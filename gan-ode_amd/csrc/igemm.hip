@@ -982,7 +982,7 @@ static bool igemm_wants_tapskip(const gode_igemm_op* op, const IgemmGeom& G) {
   return true;
 }
 
-static void choose_fast(const gode_igemm_op* op, const IgemmGeom& G, int* tile_out, SplitPlan* sp_out) {
+static void choose_fast(const gode_igemm_op* op, const IgemmGeom& G, int* tile_out, SplitPlan* sp_out, double* cycles_out = nullptr) {
   const gode_conv_geom& g = op->g;
   const int positions = g.N * G.Xd * G.Xh * G.Xw;
   const double out_bytes = 4.0 * positions * G.Ncols;
@@ -1034,6 +1034,7 @@ static void choose_fast(const gode_igemm_op* op, const IgemmGeom& G, int* tile_o
       if (cyc < best * 0.97) { best = cyc; best_tile = t; best_k = k; }   // 3 % hysteresis toward the earlier (larger) choice
     }
   }
+  if (cycles_out) *cycles_out = best;
   *tile_out = best_tile;
   sp_out->positions = positions;
   sp_out->ksplit = 1; sp_out->slabs_per_split = 0;
@@ -1096,6 +1097,19 @@ extern "C" int gode_igemm_stats_rows0(const gode_igemm_op* op) {
   IgemmArgs A; int tile, mx, rows, rows0; SplitPlan sp;
   int rc = prepare(op, &A, &tile, &mx, &rows, &sp, &rows0);
   return rc ? rc : rows0;
+}
+
+// The cost model's estimate (GPU cycles) for this op's launch, or -1 when the op does not take the modelled FAST path.
+// A caller that can run a batch as one launch or as two launches over its parts (ConvStack with split_images) compares.
+extern "C" double gode_igemm_model_cycles(const gode_igemm_op* op) {
+  if (!op || op->groups == 2 || op->tile != 0) return -1.0;
+  IgemmArgs A;
+  if (gode_build_igemm_geom(op->g, op->dir, &A.G)) return -1.0;
+  static const char* menv = getenv("GODE_IGEMM_MODEL");
+  if (!fast_geometry(A.G) || A.G.Ncols <= 4 || !strides_allow_vec(op, A.G) || (menv && atoi(menv) == 0)) return -1.0;
+  int tile; SplitPlan sp; double cyc = -1.0;
+  choose_fast(op, A.G, &tile, &sp, &cyc);
+  return cyc;
 }
 
 extern "C" int gode_igemm_stats_segments(const gode_igemm_op* op, int32_t split_images, int32_t* seg) {

@@ -14,6 +14,7 @@ import ctypes as C
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -122,15 +123,27 @@ class ConvStack:
         self.wpack_f, self.wpack_b = [], [None] * self.nl
         self.stats, self.stat_rows = [], []
         self.mean, self.invstd, self.scale, self.shift = [], [], [], []
+        # split stacks: layers whose GEMM runs as TWO launches (one per part) because the cost model prices the joint grid
+        # above the two parts' grids -- a batch of 512 + 32 images whose 512 fill whole rounds of 256 workgroups exactly
+        # spills 6 % of a round into a round of its own.  Everything else of the layer (statistics finalize, BatchNorm
+        # apply / backward, weight gradient) still runs once over all rows.
+        self._two_f, self._two_b, self._rows_ab = {}, {}, {}
         for l, s in enumerate(specs):
             n = lib.gode_pack_size(C.byref(s.geom), s.fwd_dir)
             if n <= 0:
                 raise RuntimeError(f"bad geometry for pack ({n})")
             self.wpack_f.append(self._shared_pack(l, s.fwd_dir, n))
             C_out = s.out_dims()[4]
+            two = self._two_f[l] = bool(self.split) and 0 < l < self.nl - 1 and self._two_launches(s.geom, s.fwd_dir)
             if s.has_bn:
                 probe = L.IgemmOp(g=s.geom, dir=s.fwd_dir, tile=0, groups=groups)
-                rows = lib.gode_igemm_stats_rows(C.byref(probe))
+                if two:     # the parts' partial sums: two arrays [2][ncols][rows of the part], one after the other
+                    ra, rb = (lib.gode_igemm_stats_rows(C.byref(L.IgemmOp(g=self._part_geom(s.geom, n), dir=s.fwd_dir, tile=0)))
+                              for n in (self.split, s.geom.N - self.split))
+                    rows = ra + rb if ra > 0 and rb > 0 else -1
+                    self._rows_ab[l] = (ra, rb)
+                else:
+                    rows = lib.gode_igemm_stats_rows(C.byref(probe))
                 if rows <= 0:
                     raise RuntimeError(f"layer {l}: no partial-statistics layout for this geometry ({rows})")
                 ncols = self._ncols(s)
@@ -140,7 +153,7 @@ class ConvStack:
                 ng = 2 if self._G2 else 1
                 self.mean.append(torch.empty(ng * C_out, **f32)); self.invstd.append(torch.empty(ng * C_out, **f32))
                 self.scale.append(torch.empty(ng * C_out, **f32)); self.shift.append(torch.empty(ng * C_out, **f32))
-                if self.split:
+                if self.split and not two:
                     seg = (C.c_int32 * 24)()
                     nseg = lib.gode_igemm_stats_segments(C.byref(probe), self.split, seg)
                     if nseg <= 0:
@@ -268,6 +281,19 @@ class ConvStack:
         return tuple((p.weight._version, getattr(p.weight, "_gode_ver", 0)) for p in self.params)
 
     # -- forward -------------------------------------------------------------------------------------------
+    @staticmethod
+    def _part_geom(g, n):
+        h = L.ConvGeom(*g.key())
+        h.N = n
+        return h
+
+    def _two_launches(self, g, direction):
+        """Split stack: is this layer's GEMM cheaper as one launch per part (cost model of the library)?"""
+        lib = L.lib()
+        cost = [lib.gode_igemm_model_cycles(C.byref(L.IgemmOp(g=self._part_geom(g, n), dir=direction, tile=0)))
+                for n in (g.N, self.split, g.N - self.split)]
+        return min(cost) > 0 and cost[1] + cost[2] + 12000.0 < cost[0]        # (+ ~5 us for the second launch)
+
     def _half_geom(self, g):
         h = L.ConvGeom(*g.key())
         h.N = g.N // 2
@@ -319,12 +345,22 @@ class ConvStack:
                     raise RuntimeError("a one-layer stack cannot use the GEMM + col2im head")
                 continue
             want_stats = s.has_bn and training
-            op = L.IgemmOp(g=s.geom, dir=s.fwd_dir, act=act, epilogue=s.epilogue, tile=0, src=dptr(src),
-                           wpack=dptr(self.wpack_f[l]), out=dptr(self.y[l]) if l < self.nl - 1 else None,
-                           scale=dptr(sc), shift=dptr(sh),
-                           stats=dptr(self.stats[l]) if want_stats else None,
-                           groups=2 if (G2 and s.has_bn) else 0)
-            ops.append(op)
+            if self._two_f.get(l):
+                ra = self._rows_ab[l][0] if s.has_bn else 0
+                per_in, per_out = int(np.prod(s.in_dims()[1:])), int(np.prod(s.out_dims()[1:]))
+                for n, img0, st_off in ((self.split, 0, 0), (s.geom.N - self.split, self.split, ra * 2 * self._ncols(s))):
+                    ops.append(L.IgemmOp(g=self._part_geom(s.geom, n), dir=s.fwd_dir, act=act, epilogue=s.epilogue, tile=0,
+                                         src=src.data_ptr() + 4 * img0 * per_in, wpack=dptr(self.wpack_f[l]),
+                                         out=self.y[l].data_ptr() + 4 * img0 * per_out, scale=dptr(sc), shift=dptr(sh),
+                                         stats=self.stats[l].data_ptr() + 4 * st_off if want_stats else None, groups=0))
+                op = None
+            else:
+                op = L.IgemmOp(g=s.geom, dir=s.fwd_dir, act=act, epilogue=s.epilogue, tile=0, src=dptr(src),
+                               wpack=dptr(self.wpack_f[l]), out=dptr(self.y[l]) if l < self.nl - 1 else None,
+                               scale=dptr(sc), shift=dptr(sh),
+                               stats=dptr(self.stats[l]) if want_stats else None,
+                               groups=2 if (G2 and s.has_bn) else 0)
+                ops.append(op)
             if l == 0:
                 patch["first"] = op
             if l == self.nl - 1:
@@ -341,11 +377,17 @@ class ConvStack:
                                      training=1 if training else 0, groups=self.groups if G2 else 0, rows0=rows0)
                 if self.split:
                     per_img = self._count(l) // s.geom.N
-                    nseg, seg = self._segs[l]
-                    fin.groups, fin.nseg, fin.order = 2, nseg, self.split_order
+                    fin.groups, fin.order = 2, self.split_order
                     fin.count, fin.count1 = per_img * self.split, per_img * (s.geom.N - self.split)
-                    for k in range(3 * nseg):
-                        fin.seg[k] = seg[k]
+                    if self._two_f.get(l):
+                        ra, rb = self._rows_ab[l]
+                        fin.rows, fin.rows1 = ra, rb
+                        fin.stats1 = self.stats[l].data_ptr() + 4 * ra * 2 * self._ncols(s)
+                    else:
+                        nseg, seg = self._segs[l]
+                        fin.nseg = nseg
+                        for k in range(3 * nseg):
+                            fin.seg[k] = seg[k]
                 ops.append(fin)
             if l < self.nl - 1 and self.a[l] is not None:
                 d = s.out_dims()
@@ -465,13 +507,22 @@ class ConvStack:
                 bpacks.append((l, rev, L.PackOp(g=s.geom, dir=rev, co_canon=0, w=dptr(p.weight),
                                                 wpack=dptr(self.wpack_b[l]), co_perm=dptr(s.co_perm))))
                 dst = self.g_in if l == 0 else self.g[l - 1]
-                ig = L.IgemmOp(g=s.geom, dir=rev, act=L.ACT_NONE, epilogue=L.EPI_RAW, tile=0, src=dptr(self.g[l]),
-                               wpack=dptr(self.wpack_b[l]), out=dptr(dst))
-                if l == self.nl - 1 and "tanh" not in patch:
-                    readers.append((ig, "src"))
-                if l == 0:
-                    patch["dgrad0"] = ig        # its output (the input gradient) is allocated per call
-                ops.append(ig)
+                if l not in self._two_b:
+                    self._two_b[l] = bool(self.split) and 0 < l < self.nl - 1 and self._two_launches(s.geom, rev)
+                if self._two_b[l]:        # (split stack: one launch per part, see _two_f)
+                    per_in, per_out = int(np.prod(s.in_dims()[1:])), int(np.prod(s.out_dims()[1:]))
+                    for n, img0 in ((self.split, 0), (s.geom.N - self.split, self.split)):
+                        ops.append(L.IgemmOp(g=self._part_geom(s.geom, n), dir=rev, act=L.ACT_NONE, epilogue=L.EPI_RAW, tile=0,
+                                             src=self.g[l].data_ptr() + 4 * img0 * per_out, wpack=dptr(self.wpack_b[l]),
+                                             out=dst.data_ptr() + 4 * img0 * per_in))
+                else:
+                    ig = L.IgemmOp(g=s.geom, dir=rev, act=L.ACT_NONE, epilogue=L.EPI_RAW, tile=0, src=dptr(self.g[l]),
+                                   wpack=dptr(self.wpack_b[l]), out=dptr(dst))
+                    if l == self.nl - 1 and "tanh" not in patch:
+                        readers.append((ig, "src"))
+                    if l == 0:
+                        patch["dgrad0"] = ig        # its output (the input gradient) is allocated per call
+                    ops.append(ig)
             if l > 0:
                 sp, pp = self.specs[l - 1], self.params[l - 1]
                 M, Cc = self._count(l - 1), sp.out_dims()[4]

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GODE_VERSION 102
+#define GODE_VERSION 103
 
 enum { GODE_OK = 0, GODE_E_ARG = -1, GODE_E_SHAPE = -2, GODE_E_KIND = -3 };
 enum { GODE_ACT_NONE = 0, GODE_ACT_RELU = 1, GODE_ACT_LRELU = 2,              /* LeakyReLU slope is 0.2 */
@@ -79,6 +79,9 @@ int gode_igemm_stats_rows0(const gode_igemm_op* op);
  * {begin, split, end} (gode_bn_finalize_op.seg) and returns their number; GODE_E_SHAPE when a tile (or split-K statistics
  * chunk) of this op would straddle the boundary -- the caller then runs the two parts separately. */
 int gode_igemm_stats_segments(const gode_igemm_op* op, int32_t split_images, int32_t* seg);
+/* The launch-time estimate (GPU cycles) of the tile / split-K cost model for this op, or -1 when the op does not take the
+ * modelled path.  Host-side, no GPU work: such a caller compares one launch over the whole batch with two over its parts. */
+double gode_igemm_model_cycles(const gode_igemm_op* op);
 /* floats needed for the packed weights of (geom, dir) */
 int64_t gode_pack_size(const gode_conv_geom* g, int dir);
 /* canonical W[co][ci][taps] -> packed panels.  co_perm (nullable, length g->Co): internal y-side channel c is
@@ -127,6 +130,9 @@ typedef struct gode_bn_finalize_op {
    * rows are [first batch; second batch]); count1 (> 0): elements per channel of group 1 when the groups differ in size
    * (count: group 0); order != 0: group 1's momentum update is applied first (the reference called that batch first). */
   int32_t nseg, order; int64_t count1; int32_t seg[24];   /* 8 x {begin, split, end} */
+  /* groups == 2, two-launch form (overrides nseg / rows0): group 1's partial sums are an array of their own,
+   * stats1[2][ncols][rows1], written by a second gode_igemm launch over that batch alone; `stats` / `rows` are group 0's. */
+  const float* stats1; int32_t rows1, pad3_;
 } gode_bn_finalize_op;
 int gode_bn_finalize(const gode_bn_finalize_op* op, void* stream);
 
