@@ -37,6 +37,7 @@ struct IgemmArgs {
   float* work;
   int32_t out_numel;
   int32_t stats_rows;   // number of partial-statistics rows of the launch (the stats buffer is [2][ncols][stats_rows])
+  uint32_t src_bytes, w_bytes;   // LDS-DMA kernels address both operands as raw buffers (32-bit byte offsets): their extents
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs in linear id order (id and id+8 share an XCD and its 4 MiB L2);
@@ -287,6 +288,32 @@ __device__ __attribute__((aligned(16))) const float gode_zero16[4] = {0.f, 0.f, 
 //           tensor's ends in the input gradient of a temporal k=4 convolution, 23-43 % of the K loop of the UCF video
 //           discriminator's layers -- are left out of a per-tile tap table (workgroup-uniform).  Its own instantiation:
 //           the bookkeeping costs the plain MODE 2 loop 5-12 % when compiled in.
+// Raw-buffer view of an operand for the LDS-DMA loads (the resource type and its builtins exist in the device pass only; the
+// host pass, which only needs the kernel's launch stub, sees empty shells).
+struct BufRsrc {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t r;
+#endif
+};
+__device__ __forceinline__ BufRsrc make_buf_rsrc(const float* p, uint32_t bytes) {
+  BufRsrc b;
+#if defined(__HIP_DEVICE_COMPILE__)
+  b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);   // raw buffer, 32-bit words
+#else
+  (void)p; (void)bytes;
+#endif
+  return b;
+}
+// 16 bytes per lane, memory[voff + soff] -> LDS[lds + 16 * lane]: voff per lane (VGPR), soff wave-uniform (SGPR); a voff beyond
+// the buffer's extent delivers zeros
+__device__ __forceinline__ void buf_dma16(const BufRsrc& b, float* lds, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+#else
+  (void)b; (void)lds; (void)voff; (void)soff;
+#endif
+}
+
 template <int WM, int WN, int TM, int TN, int MODE, bool XF>
 __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs a) {
   constexpr bool DB = MODE == 1, GL = MODE >= 2, SK = MODE == 3;
@@ -408,6 +435,19 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
   unsigned amask = 0;
   int roff[AP];          // element offset of (row, current tap, channel 0); refreshed only when the tap changes
   bool tap_dirty = true;
+  // GL: both operands are raw buffers.  A lane's byte offset (row, tap, K chunk) sits in a VGPR and changes once per tap; the
+  // per-slab advance is the instruction's SCALAR offset, so issuing a slab costs one s_mov m0 + one buffer_load ... lds per
+  // 1 KiB piece and no vector arithmetic.  Padding taps and tail rows carry an offset beyond the buffer: the hardware's
+  // range check returns zeros for them (no zero page, no select).
+  BufRsrc rsrcA, rsrcB;
+  unsigned voffB[BP];
+  if (GL) {
+    rsrcA = make_buf_rsrc(a.src, a.src_bytes);
+    rsrcB = make_buf_rsrc(a.w, a.w_bytes);
+#pragma unroll
+    for (int i = 0; i < BP; ++i) voffB[i] = (unsigned)((wrow[i] - a.w) * 4);
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
   auto tap_refresh = [&]() {
     if (tap_dirty) {     // wave-uniform: once per tap (every Cg/32 slabs), not per slab
@@ -443,19 +483,20 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
   };
   // LDS-DMA issue of one slab into buffer `buf`: wave w fills rows 8w..8w+7 (+RPP per pass), 1 KiB per instruction
   auto dma = [&](int slab, int buf) {
-    tap_refresh();
-    float* dstA = smem + buf * BUF + wave * 8 * LDK;
+    if (tap_dirty) {
+      tap_refresh();
+#pragma unroll
+      for (int i = 0; i < AP; ++i) roff[i] = ((amask >> i) & 1u) ? roff[i] * 4 : (int)0x80000000;     // (GL: bytes from here on)
+    }
+    float* dstA = smem + buf * BUF + wave_u * 8 * LDK;
     float* dstB = dstA + BM * LDK;
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      const float* g = ((amask >> i) & 1u) ? a.src + roff[i] + c0 : gode_zero16;   // padding taps read a zero page
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(dstA + RPP * i * LDK), 16, 0, 0);
-    }
+    for (int i = 0; i < AP; ++i)
+      buf_dma16(rsrcA, dstA + RPP * i * LDK, roff[i], c0 * 4);
+    const int kb = (SK ? wk + c0 : slab * 32) * 4;
 #pragma unroll
     for (int i = 0; i < BP; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + (SK ? wk + c0 : slab * 32)),
-                                       (__attribute__((address_space(3))) void*)(dstB + RPP * i * LDK), 16, 0, 0);
+      buf_dma16(rsrcB, dstB + RPP * i * LDK, (int)voffB[i], kb);
     advance();
   };
   auto stageA = [&](int buf) {
@@ -512,16 +553,45 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
   };
 
   if (GL) {
+    // Fragments run one MFMA group ahead of the matrix pipe, and the slab barrier sits BEFORE the last group of a slab:
+    // by then this wave has read all its fragments of the slab (so the buffer may be refilled once everyone is past the
+    // barrier) and its share of the next slab has landed; the last group's 16 MFMAs then cover the barrier's skew and the
+    // first fragment reads of the next slab -- the matrix pipe never waits for LDS or for the DMA issue.
+    f32x4 fa[2][TM], fb[2][TN];
+    auto frag = [&](int buf, int kg, int set) {
+      const int koff = ((2 * kg + fhalf) ^ fkey) * 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(Abase + buf * BUF + i * 32 * LDK + koff);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[set][j] = *reinterpret_cast<const f32x4*>(Bbase + buf * BUF + j * 32 * LDK + koff);
+    };
+    auto mma = [&](int set) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
+    };
     if (nslab > 0) {
       dma(0, 0);
+      __syncthreads();                        // (waits vmcnt(0)) slab 0 has landed
+      frag(0, 0, 0);
       for (int s = 0; s < nslab; ++s) {
-        __syncthreads();                      // waits vmcnt(0): slab s has landed; every wave is done with slab s-1
-        if (s + 1 < nslab) dma(s + 1, (s + 1) & 1);
         const int buf = s & 1;
-        mma_group(buf, 0); mma_group(buf, 1); mma_group(buf, 2); mma_group(buf, 3);
+        if (s + 1 < nslab) dma(s + 1, buf ^ 1);   // every wave is past the barrier below: nobody reads that buffer any more
+        // (sched_barrier: the compiler otherwise sinks each fragment read to just before its first use, i.e. behind the
+        // MFMA group it is meant to run under)
+        frag(buf, 1, 1); __builtin_amdgcn_sched_barrier(0); mma(0); __builtin_amdgcn_sched_barrier(0);
+        frag(buf, 2, 0); __builtin_amdgcn_sched_barrier(0); mma(1); __builtin_amdgcn_sched_barrier(0);
+        frag(buf, 3, 1); __builtin_amdgcn_sched_barrier(0); mma(0); __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                      // lgkmcnt(0) + vmcnt(0) + barrier: my reads of slab s are done, slab s+1 has landed
+        frag(buf ^ 1, 0, 0);                  // (after the last slab: a stale buffer, never used)
+        __builtin_amdgcn_sched_barrier(0); mma(1); __builtin_amdgcn_sched_barrier(0);
       }
-      __syncthreads();
     }
+    __syncthreads();                          // the epilogue reuses the buffers
   } else if (nslab > 0) {
   fetch(0);
   if (DB) {
@@ -1193,7 +1263,8 @@ static int launch(IgemmArgs& A, bool vec, int max_mblk, bool double_buf, const S
     dim3 g1(MB * NC * sp.ksplit);
     const bool has_xf = A.scale != nullptr || A.act != GODE_ACT_NONE;
     static const char* genv = getenv("GODE_IGEMM_GLDS");
-    const bool glds = genv ? atoi(genv) != 0 : true;   // default; GODE_IGEMM_GLDS=0 selects register staging
+    // default; GODE_IGEMM_GLDS=0 selects register staging (as do operands beyond the 2 GiB a raw buffer's offsets span)
+    const bool glds = (genv ? atoi(genv) != 0 : true) && A.src_bytes != 0 && A.w_bytes != 0;
     if (!has_xf && glds && !double_buf) {
       if (A.tapskip) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 3, false>), g1, block, 0, st, A);
       else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 2, false>), g1, block, 0, st, A);
@@ -1258,6 +1329,8 @@ extern "C" int gode_igemm(const gode_igemm_op* op, void* stream) {
   // faster there as well: UCF video-D layer 1 input gradient 833 -> 800 us at N = 32, 405 -> 381 at N = 16).
   if (A.tapskip) A.dmajor = op->g.N;
   A.stats_rows = rows;
+  A.src_bytes = span * 4 < (1ll << 31) ? (uint32_t)(span * 4) : 0u;
+  A.w_bytes = gode_pack_floats(G) * 4 < (1ll << 31) ? (uint32_t)(gode_pack_floats(G) * 4) : 0u;
   A.work = op->work; A.out_numel = (int32_t)outn; A.ksplit = 1; A.slabs_per_split = 0; A.MB = 0; A.NB = 0; A.xcd_mode = 0;
   if ((op->scale == nullptr) != (op->shift == nullptr)) return GODE_E_ARG;
   const bool vec = gs[4] == 1 && (G.Cg % 4) == 0 && (gs[0] % 4) == 0 && (gs[1] % 4) == 0 && (gs[2] % 4) == 0 &&
