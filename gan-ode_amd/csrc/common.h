@@ -25,6 +25,32 @@ __device__ __forceinline__ float gode_act_grad(float z, int act) {
   return 1.f;
 }
 
+// Raw-buffer view of an operand for the LDS-DMA loads (the resource type and its builtins exist in the device pass only; the
+// host pass, which only needs the kernel's launch stub, sees empty shells).
+struct BufRsrc {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t r;
+#endif
+};
+__device__ __forceinline__ BufRsrc make_buf_rsrc(const float* p, uint32_t bytes) {
+  BufRsrc b;
+#if defined(__HIP_DEVICE_COMPILE__)
+  b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);   // raw buffer, 32-bit words
+#else
+  (void)p; (void)bytes;
+#endif
+  return b;
+}
+// 16 bytes per lane, memory[voff + soff] -> LDS[lds + 16 * lane]: voff per lane (VGPR), soff wave-uniform (SGPR); a voff beyond
+// the buffer's extent delivers zeros
+__device__ __forceinline__ void buf_dma16(const BufRsrc& b, float* lds, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+#else
+  (void)b; (void)lds; (void)voff; (void)soff;
+#endif
+}
+
 static inline bool gode_strides_are_channels_last(const int64_t* s) { return s[0] == 0 && s[1] == 0 && s[2] == 0 && s[3] == 0 && s[4] == 0; }
 
 // Division by a run-time invariant (Granlund-Montgomery, branch-free, exact for all 32-bit n): the host builds the

@@ -288,32 +288,6 @@ __device__ __attribute__((aligned(16))) const float gode_zero16[4] = {0.f, 0.f, 
 //           tensor's ends in the input gradient of a temporal k=4 convolution, 23-43 % of the K loop of the UCF video
 //           discriminator's layers -- are left out of a per-tile tap table (workgroup-uniform).  Its own instantiation:
 //           the bookkeeping costs the plain MODE 2 loop 5-12 % when compiled in.
-// Raw-buffer view of an operand for the LDS-DMA loads (the resource type and its builtins exist in the device pass only; the
-// host pass, which only needs the kernel's launch stub, sees empty shells).
-struct BufRsrc {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __amdgpu_buffer_rsrc_t r;
-#endif
-};
-__device__ __forceinline__ BufRsrc make_buf_rsrc(const float* p, uint32_t bytes) {
-  BufRsrc b;
-#if defined(__HIP_DEVICE_COMPILE__)
-  b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);   // raw buffer, 32-bit words
-#else
-  (void)p; (void)bytes;
-#endif
-  return b;
-}
-// 16 bytes per lane, memory[voff + soff] -> LDS[lds + 16 * lane]: voff per lane (VGPR), soff wave-uniform (SGPR); a voff beyond
-// the buffer's extent delivers zeros
-__device__ __forceinline__ void buf_dma16(const BufRsrc& b, float* lds, int voff, int soff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
-#else
-  (void)b; (void)lds; (void)voff; (void)soff;
-#endif
-}
-
 template <int WM, int WN, int TM, int TN, int MODE, bool XF>
 __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs a) {
   constexpr bool DB = MODE == 1, GL = MODE >= 2, SK = MODE == 3;

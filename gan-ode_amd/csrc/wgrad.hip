@@ -20,6 +20,7 @@ struct WgradArgs {
   int32_t act, xform_on_y;
   int32_t M, chunk, Kt, taps;
   FastDiv dWo, dHo, dDo;
+  uint32_t x_bytes;     // extent of x (LDS-DMA kernels address the operands as raw buffers: 32-bit byte offsets); 0: too large
 };
 
 template <int WM, int WN, int TM, int TN, bool VECX, bool VECY>
@@ -175,7 +176,6 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_kernel(const WgradArgs a) {
 
 // FAST path (vector loads on both operands): branch-free loop body (clamped loads + masks, magic-number position
 // decode).  GL=false: register staging into ONE LDS buffer (32 KB at 128x128), BN/activation fused into the load.
-__device__ __attribute__((aligned(16))) const float gode_wg_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 // GL: transform-free operands go global -> LDS by `global_load_lds_dwordx4` (the [position][channel] image is already
 // lane-linear: thread t of a loader pass owns 16-byte chunk t), two LDS buffers, one barrier per 32-position slab.
@@ -237,33 +237,65 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_fast_kernel(const WgradArgs
       xmask |= (ok ? 1u : 0u) << p;
     }
   };
-  // LDS-DMA issue of one slab: the loader's (row, chunk) of a pass is tid-linear, so wave w writes 1 KiB at
-  // pass base + 256*w floats; masked rows (tail, padding taps) read a zero page
-  auto dma = [&](int slab, int buf) {
-    const int mb = m_begin + slab * 32;
-    float* Ys = smem + buf * BUF + wave * 256;
-    float* Xs = smem + buf * BUF + 32 * BI + wave * 256;
+  // LDS-DMA issue of one slab (GL): the loader's (row, chunk) of a pass is tid-linear, so wave w writes 1 KiB at pass base +
+  // 256*w floats.  Both operands are raw buffers.  y: the resource is re-based to the slab (three scalar operations), a lane's
+  // offset inside the slab is a constant, and the rows past m_end fall outside the re-based extent (zeros from the range
+  // check).  x: the position (image, depth, row, column) of a lane's rows is carried from slab to slab -- a slab advances
+  // every row by 32 positions, i.e. by fixed digit increments with at most one carry per digit -- instead of being decoded
+  // from the row number with three divisions per load; padding taps and tail rows get an offset beyond the buffer.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  BufRsrc rsrcX;
+  int yvoff[YP];
+  int xm[XP], xiw[XP], xih[XP], xid[XP], xoff[XP];
+  // digit increments of a 32-position step and the offset corrections of the carries (wave-uniform)
+  const int stepw = 32 % g.Wo, c1 = 32 / g.Wo, steph = c1 % g.Ho, c2 = c1 / g.Ho, stepd = c2 % g.Do, stepn = c2 / g.Do;
+  const int spanw = g.Wo * g.sw, spanh = g.Ho * g.sh, spand = g.Do * g.sd;
+  const int off_step = stepw * g.sw * a.xsW + steph * g.sh * a.xsH + stepd * g.sd * a.xsD + stepn * a.xsN;
+  const int off_cw = g.sh * a.xsH - spanw * a.xsW, off_ch = g.sd * a.xsD - spanh * a.xsH, off_cd = a.xsN - spand * a.xsD;
+  const int iw_lim = xkw - g.pw + spanw, ih_lim = xkh - g.ph + spanh, id_lim = xkd - g.pd + spand;
+  if (GL) {
+    rsrcX = make_buf_rsrc(a.x, a.x_bytes);
 #pragma unroll
-    for (int p = 0; p < YP; ++p) {
-      const int m = mb + yr0 + p * YR;
-      const bool ok = m < m_end && yok;
-      const float* gp = ok ? yptr + (int64_t)m * g.Co : gode_wg_zero16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                       (__attribute__((address_space(3))) void*)(Ys + p * YR * BI), 16, 0, 0);
-    }
+    for (int p = 0; p < YP; ++p) yvoff[p] = yok ? ((yr0 + p * YR) * g.Co + co0) * 4 : (int)0x80000000;
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
-      const uint32_t m = mb + xr0 + p * XR;
+      const uint32_t m = m_begin + xr0 + p * XR;
       const uint32_t t1 = fdiv(m, a.dWo), qw = m - t1 * g.Wo;
       const uint32_t t2 = fdiv(t1, a.dHo), qh = t1 - t2 * g.Ho;
       const uint32_t img = fdiv(t2, a.dDo), qd = t2 - img * g.Do;
-      const int id = (int)qd * g.sd - g.pd + xkd, ih = (int)qh * g.sh - g.ph + xkh, iw = (int)qw * g.sw - g.pw + xkw;
-      const bool ok = (int)m < m_end && xok && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi &&
-                      (unsigned)iw < (unsigned)g.Wi;
-      const float* gp = ok ? xptr + ((int)img * a.xsN + id * a.xsD + ih * a.xsH + iw * a.xsW) : gode_wg_zero16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                       (__attribute__((address_space(3))) void*)(Xs + p * XR * BJ), 16, 0, 0);
+      xm[p] = (int)m;
+      xid[p] = (int)qd * g.sd - g.pd + xkd; xih[p] = (int)qh * g.sh - g.ph + xkh; xiw[p] = (int)qw * g.sw - g.pw + xkw;
+      xoff[p] = (int)img * a.xsN + xid[p] * a.xsD + xih[p] * a.xsH + xiw[p] * a.xsW + xci;
     }
+  }
+  int dma_mb = m_begin;          // first position of the slab the next dma() call fetches (slabs are fetched in order)
+  auto dma = [&](int buf) {
+    float* Ys = smem + buf * BUF + wave_u * 256;
+    float* Xs = smem + buf * BUF + 32 * BI + wave_u * 256;
+    const int left = m_end - dma_mb;
+    const BufRsrc rsrcY = make_buf_rsrc(a.y + (int64_t)dma_mb * g.Co, (uint32_t)((left > 32 ? 32 : left) * g.Co) * 4u);
+#pragma unroll
+    for (int p = 0; p < YP; ++p) buf_dma16(rsrcY, Ys + p * YR * BI, yvoff[p], 0);
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const bool ok = xm[p] < m_end && xok && (unsigned)xid[p] < (unsigned)g.Di && (unsigned)xih[p] < (unsigned)g.Hi &&
+                      (unsigned)xiw[p] < (unsigned)g.Wi;
+      buf_dma16(rsrcX, Xs + p * XR * BJ, ok ? xoff[p] * 4 : (int)0x80000000, 0);
+      // advance this row by 32 positions
+      xm[p] += 32;
+      int o = xoff[p] + off_step;
+      int iw = xiw[p] + stepw * g.sw;
+      const bool cw = iw >= iw_lim;
+      iw -= cw ? spanw : 0; o += cw ? off_cw : 0;
+      int ih = xih[p] + steph * g.sh + (cw ? g.sh : 0);
+      const bool ch = ih >= ih_lim;
+      ih -= ch ? spanh : 0; o += ch ? off_ch : 0;
+      int id = xid[p] + stepd * g.sd + (ch ? g.sd : 0);
+      const bool cd = id >= id_lim;
+      id -= cd ? spand : 0; o += cd ? off_cd : 0;
+      xiw[p] = iw; xih[p] = ih; xid[p] = id; xoff[p] = o;
+    }
+    dma_mb += 32;
   };
   auto stage = [&]() {
     float* Ys = smem;
@@ -313,12 +345,37 @@ __global__ void __launch_bounds__(WM* WN * 64) wgrad_fast_kernel(const WgradArgs
     }
   };
   if (GL) {
+    // same schedule as igemm_fast_kernel's LDS-DMA loop: fragments one group of 16 MFMAs (4 k pairs) ahead of the matrix
+    // pipe, the slab barrier before the last group
+    av_t fa[2][4]; bv_t fb[2][4];
+    auto frag = [&](int buf, int kg, int set) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        fa[set][q] = *reinterpret_cast<const av_t*>(Yr + buf * BUF + (kg * 4 + q) * 2 * BI);
+        fb[set][q] = *reinterpret_cast<const bv_t*>(Xr + buf * BUF + (kg * 4 + q) * 2 * BJ);
+      }
+    };
+    auto mma = [&](int set) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][q][i], fb[set][q][j], acc[i][j], 0, 0, 0);
+    };
     if (nslab > 0) {
-      dma(0, 0);
+      dma(0);
+      __syncthreads();                   // (waits vmcnt(0)) slab 0 has landed
+      frag(0, 0, 0);
       for (int s = 0; s < nslab; ++s) {
-        __syncthreads();                 // waits vmcnt(0): slab s has landed; every wave is done with slab s-1
-        if (s + 1 < nslab) dma(s + 1, (s + 1) & 1);
-        mma_slab(s & 1);
+        const int buf = s & 1;
+        if (s + 1 < nslab) dma(buf ^ 1);
+        frag(buf, 1, 1); __builtin_amdgcn_sched_barrier(0); mma(0); __builtin_amdgcn_sched_barrier(0);
+        frag(buf, 2, 0); __builtin_amdgcn_sched_barrier(0); mma(1); __builtin_amdgcn_sched_barrier(0);
+        frag(buf, 3, 1); __builtin_amdgcn_sched_barrier(0); mma(0); __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                 // my reads of slab s are done, slab s+1 has landed (vmcnt(0) + barrier)
+        frag(buf ^ 1, 0, 0);             // (after the last slab: a stale buffer, never used)
+        __builtin_amdgcn_sched_barrier(0); mma(1); __builtin_amdgcn_sched_barrier(0);
       }
     }
   } else if (nslab > 0) {
@@ -811,7 +868,7 @@ static int wg_launch(const WgradArgs& A, bool vx, bool vy, int splits, hipStream
   constexpr int BI = WM * TM * 32, BJ = WN * TN * 32;
   dim3 grid(gode_ceil_div(A.Kt, BJ), gode_ceil_div(A.g.Co, BI), splits), block(WM * WN * 64);
   static const char* genv = getenv("GODE_WGRAD_GLDS");
-  const bool glds = (genv ? atoi(genv) != 0 : true) && A.scale == nullptr && A.act == GODE_ACT_NONE;
+  const bool glds = (genv ? atoi(genv) != 0 : true) && A.scale == nullptr && A.act == GODE_ACT_NONE && A.x_bytes != 0;
   if (vx && vy && !wg_generic_forced()) {
     if (glds) hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, true>), grid, block, 0, st, A);
     else hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, false>), grid, block, 0, st, A);
@@ -844,6 +901,7 @@ extern "C" int gode_wgrad(const gode_wgrad_op* op, void* stream) {
   if (span >= (1ll << 31) || M * g.Co >= (1ll << 31)) return GODE_E_SHAPE;
   A.xsN = (int)xs[0]; A.xsD = (int)xs[1]; A.xsH = (int)xs[2]; A.xsW = (int)xs[3]; A.xsC = (int)xs[4];
   A.act = op->act; A.xform_on_y = op->xform_on_y;
+  A.x_bytes = (span * 4 < (1ll << 31) && M * g.Co * 4 < (1ll << 31)) ? (uint32_t)(span * 4) : 0u;
   A.M = (int)M; A.taps = g.kd * g.kh * g.kw; A.Kt = A.taps * g.Ci;
   A.dWo = make_fastdiv(g.Wo); A.dHo = make_fastdiv(g.Ho); A.dDo = make_fastdiv(g.Do);
   const int splits = wg_splits(op);
@@ -879,7 +937,7 @@ extern "C" int gode_wgrad(const gode_wgrad_op* op, void* stream) {
   else if (t == 1) rc = wg_launch<2, 2, 1, 2>(A, vx, vy, splits, st);
   else if (t >= 3 && vx && vy && !wg_generic_forced()) {
     dim3 grid(gode_ceil_div(A.Kt, wg_bj(t)), gode_ceil_div(g.Co, wg_bi(t)), splits), block(512);
-    const bool glds = A.scale == nullptr && A.act == GODE_ACT_NONE;
+    const bool glds = A.scale == nullptr && A.act == GODE_ACT_NONE && A.x_bytes != 0;
     if (t == 3) {
       if (glds) hipLaunchKernelGGL((wgrad_fast_kernel<4, 2, 2, 2, true>), grid, block, 0, st, A);
       else hipLaunchKernelGGL((wgrad_fast_kernel<4, 2, 2, 2, false>), grid, block, 0, st, A);

@@ -56,3 +56,25 @@ for name, g in cases:
         tot += us
         print(f"{name:20s} {dn}  {us:7.1f} us  {fl/us/1e6:6.1f} TF   sum {float(out.double().sum()):.6e} sq {float((out.double()**2).sum()):.6e}", flush=True)
 print(f"total {tot:.1f} us   lib {L.LIB_PATH}")
+tot = 0.0
+wcases = [(n, g) for n, g in cases if not n.startswith("dec L3 N=544")] + [("dec L2 N=544", make_geom(544, 128, 256, (1, 16, 16), (1, 8, 8), (1, 4, 4), (1, 2, 2), (0, 1, 1)))]
+for name, g in wcases:
+    x = torch.randn(g.N, g.Di, g.Hi, g.Wi, g.Ci, device="cuda")
+    y = torch.randn(g.N, g.Do, g.Ho, g.Wo, g.Co, device="cuda")
+    dw = torch.zeros(g.Co, g.Ci, g.kd, g.kh, g.kw, device="cuda")
+    op = L.WgradOp(g=g, act=L.ACT_NONE, xform_on_y=0, splits=0, accumulate=0, x=x.data_ptr(), y=y.data_ptr(), scale=None, shift=None, dw=dw.data_ptr())
+    work = torch.empty(lib.gode_wgrad_work_size(C.byref(op)), device="cuda")
+    op.work = work.data_ptr()
+    st = stream_ptr()
+    for _ in range(3):
+        L.run_one(op, st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        L.run_one(op, st)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    tot += us
+    fl = 2.0 * g.N * g.Do * g.Ho * g.Wo * g.Co * g.Ci * g.kd * g.kh * g.kw
+    print(f"{name:20s} wgrad  {us:7.1f} us  {fl/us/1e6:6.1f} TF   sum {float(dw.double().sum()):.6e} sq {float((dw.double()**2).sum()):.6e}", flush=True)
+print(f"wgrad total {tot:.1f} us")
