@@ -552,6 +552,24 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_fast_kernel(const IgemmArgs
       dma(0, 0);
       __syncthreads();                        // (waits vmcnt(0)) slab 0 has landed
       frag(0, 0, 0);
+#ifdef GODE_ABLATION_BUILD   // timing-only bodies (WRONG results); never defined for libgode.so (scripts/exp/build_ablation.sh)
+      if (a.stagger < 0) {
+        const bool rd = a.stagger >= -2 || a.stagger == -4;      // -3: MFMAs only; -1: + fragment reads; -2: + barrier; -4: all but the barrier
+        for (int s = 0; s < nslab; ++s) {
+          const int buf = s & 1;
+          if (a.stagger == -4 && s + 1 < nslab) dma(s + 1, buf ^ 1);
+          if (rd) frag(buf, 1, 1);
+          __builtin_amdgcn_sched_barrier(0); mma(0); __builtin_amdgcn_sched_barrier(0);
+          if (rd) frag(buf, 2, 0);
+          __builtin_amdgcn_sched_barrier(0); mma(1); __builtin_amdgcn_sched_barrier(0);
+          if (rd) frag(buf, 3, 1);
+          __builtin_amdgcn_sched_barrier(0); mma(0); __builtin_amdgcn_sched_barrier(0);
+          if (a.stagger == -2) __syncthreads();
+          if (rd) frag(buf ^ 1, 0, 0);
+          __builtin_amdgcn_sched_barrier(0); mma(1); __builtin_amdgcn_sched_barrier(0);
+        }
+      } else
+#endif
       for (int s = 0; s < nslab; ++s) {
         const int buf = s & 1;
         if (s + 1 < nslab) dma(s + 1, buf ^ 1);   // every wave is past the barrier below: nobody reads that buffer any more
