@@ -101,6 +101,7 @@ class ConvStack:
         if self.split and (groups != 1 or not owns_input or not (0 < self.split < specs[0].geom.N)):
             raise ValueError("split ConvStack: plan-owned input, one launch group, 0 < split_images < N")
         self._G2 = groups == 2 or self.split > 0          # two BatchNorm groups: [2][C] statistics arrays
+        self._last_parts = False
         if groups not in (1, 2) or (groups == 2 and (owns_input or specs[0].fwd_dir != L.FPROP or specs[0].has_bn
                                                      or specs[0].geom.N % 2)):
             raise ValueError("grouped ConvStack: two groups, Conv stack, caller-owned input, no BatchNorm on layer 0")
@@ -218,12 +219,19 @@ class ConvStack:
             return False
         prod, cons = self.specs[l], self.specs[l + 1]
         C_out = prod.out_dims()[4]
-        if self._G2 and prod.has_bn:
-            return True      # per-group scale/shift: consumers read the activated copy, nothing downstream knows of groups
         g = cons.geom
         taps = g.kd * g.kh * g.kw
         macs = g.N * g.Do * g.Ho * g.Wo * g.Co * g.Ci * taps
-        return C_out % 32 == 0 and macs >= (1 << 30) and (prod.has_bn or prod.act != L.ACT_NONE)
+        heavy = C_out % 32 == 0 and macs >= (1 << 30) and (prod.has_bn or prod.act != L.ACT_NONE)
+        if self._G2 and prod.has_bn:
+            # per-group scale/shift: consumers read the activated copy, nothing downstream knows of groups -- except the light
+            # LAST layer of a split stack (the generator's output convolution: its input is the largest activation of the
+            # pass), which runs as one launch per part with that part's scale / shift instead (self._last_parts)
+            if self.split and not heavy and l + 1 == self.nl - 1 and cons.epilogue == L.EPI_TANH and not cons.has_bn:
+                self._last_parts = True
+                return False
+            return True
+        return heavy
 
     def _head_as_gemm(self, l):
         """A thin-output ConvTranspose2d at the end of the stack (<= 4 output channels, > 1 tap, many pixels: the UCF
@@ -335,8 +343,17 @@ class ConvStack:
                 g = s.geom
                 if getattr(self, "_head_cols", None) is None:
                     self._head_cols = torch.empty(hg.N * g.kh * g.kw * g.Ci, dtype=torch.float32, device=self.device)
-                ops.append(L.IgemmOp(g=hg, dir=L.DGRAD, act=act, epilogue=L.EPI_RAW, tile=0, src=dptr(src), wpack=dptr(wp),
-                                     out=dptr(self._head_cols), scale=dptr(sc), shift=dptr(sh)))
+                if self._last_parts:      # one pixel GEMM per part (that part's BatchNorm scale / shift), one overlap-add
+                    pix, Cs = g.Ho * g.Wo, sc.numel() // 2
+                    for n, img0, k in ((self.split, 0, 0), (g.N - self.split, self.split, 1)):
+                        pg = self._part_geom(hg, n * pix)
+                        ops.append(L.IgemmOp(g=pg, dir=L.DGRAD, act=act, epilogue=L.EPI_RAW, tile=0,
+                                             src=src.data_ptr() + 4 * img0 * pix * g.Co, wpack=dptr(wp),
+                                             out=self._head_cols.data_ptr() + 4 * img0 * pix * g.kh * g.kw * g.Ci,
+                                             scale=sc.data_ptr() + 4 * Cs * k, shift=sh.data_ptr() + 4 * Cs * k))
+                else:
+                    ops.append(L.IgemmOp(g=hg, dir=L.DGRAD, act=act, epilogue=L.EPI_RAW, tile=0, src=dptr(src), wpack=dptr(wp),
+                                         out=dptr(self._head_cols), scale=dptr(sc), shift=dptr(sh)))
                 c2i = L.Col2imOp(cols=dptr(self._head_cols), out=None, N=g.N, Hi=g.Ho, Wi=g.Wo, Ho=g.Hi, Wo=g.Wi, C=g.Ci,
                                  kh=g.kh, kw=g.kw, sh=g.sh, sw=g.sw, ph=g.ph, pw=g.pw, epilogue=s.epilogue)
                 ops.append(c2i)
@@ -345,6 +362,17 @@ class ConvStack:
                     raise RuntimeError("a one-layer stack cannot use the GEMM + col2im head")
                 continue
             want_stats = s.has_bn and training
+            if self._last_parts and l == self.nl - 1:
+                # (split stack, light output layer: one launch per part with that part's BatchNorm scale / shift)
+                per_in, per_out, Cs = int(np.prod(s.in_dims()[1:])), int(np.prod(s.out_dims()[1:])), sc.numel() // 2
+                pair = []
+                for n, img0, k in ((self.split, 0, 0), (s.geom.N - self.split, self.split, 1)):
+                    pair.append(L.IgemmOp(g=self._part_geom(s.geom, n), dir=s.fwd_dir, act=act, epilogue=s.epilogue, tile=0,
+                                          src=src.data_ptr() + 4 * img0 * per_in, wpack=dptr(self.wpack_f[l]), out=None,
+                                          scale=sc.data_ptr() + 4 * Cs * k, shift=sh.data_ptr() + 4 * Cs * k))
+                ops += pair
+                patch["last"], patch["last2"] = pair[0], (pair[1], 4 * self.split * per_out)
+                continue
             if self._two_f.get(l):
                 ra = self._rows_ab[l][0] if s.has_bn else 0
                 per_in, per_out = int(np.prod(s.in_dims()[1:])), int(np.prod(s.out_dims()[1:]))
@@ -410,6 +438,8 @@ class ConvStack:
         prog, patch = self._fwd[training]
         out = torch.empty(self.out_dims, dtype=torch.float32, device=self.device)
         patch["last"].out = out.data_ptr()
+        if "last2" in patch:
+            patch["last2"][0].out = out.data_ptr() + patch["last2"][1]
         if self.x_in is None:
             first = patch["first"]
             first.src = x.data_ptr()
@@ -486,13 +516,28 @@ class ConvStack:
                 if need_input_grad:
                     raise NotImplementedError("a grouped stack does not return input gradients")
                 continue
-            if s.fwd_dir == L.FPROP:
+            if self._last_parts and l == self.nl - 1:
+                # (split stack, light output layer: its input is read raw with the PART's BatchNorm scale / shift -- one
+                # weight-gradient launch per part, the second adds to the first)
+                if s.fwd_dir != L.DGRAD or "tanh" not in patch:
+                    raise NotImplementedError("split stack: per-part output layer is a transposed convolution with tanh")
+                per_in, per_out, Cs = int(np.prod(s.in_dims()[1:])), int(np.prod(s.out_dims()[1:])), sc.numel() // 2
+                if need_param_grad:
+                    for n, img0, k in ((self.split, 0, 0), (s.geom.N - self.split, self.split, 1)):
+                        wk = L.WgradOp(g=self._part_geom(s.geom, n), act=act, xform_on_y=1, splits=0, accumulate=0,
+                                       x=self.g[l].data_ptr() + 4 * img0 * per_out, y=src.data_ptr() + 4 * img0 * per_in,
+                                       scale=sc.data_ptr() + 4 * Cs * k, shift=sh.data_ptr() + 4 * Cs * k, co_perm=dptr(s.co_perm))
+                        wg_work = max(wg_work, lib.gode_wgrad_work_size(C.byref(wk)))
+                        patch["dw"].append((l, wk, k == 1))
+                        ops.append(wk)
+                w = None
+            elif s.fwd_dir == L.FPROP:
                 w = L.WgradOp(g=s.geom, act=act, xform_on_y=0, splits=0, accumulate=0, x=dptr(src), y=dptr(self.g[l]),
                               scale=dptr(sc), shift=dptr(sh), co_perm=dptr(s.co_perm))
             else:
                 w = L.WgradOp(g=s.geom, act=act, xform_on_y=1, splits=0, accumulate=0, x=dptr(self.g[l]), y=dptr(src),
                               scale=dptr(sc), shift=dptr(sh), co_perm=dptr(s.co_perm))
-            if need_param_grad:
+            if need_param_grad and w is not None:
                 wg_work = max(wg_work, lib.gode_wgrad_work_size(C.byref(w)))
                 patch["dw"].append((l, w, False))
                 if l == 0:
