@@ -752,8 +752,22 @@ class GanTrainer:
                 else:
                     fake_vid, _ = self.gen.sample_videos(B)
                     fake_img, _ = self.gen.sample_images(B)
-                pv, _ = self.dis_vid(fake_vid)
-                pi, _ = self.dis_img(fake_img)
+                side = self._side if shards == 1 else None
+                if side is not None:
+                    # D_img(fake images) -- ~40 launches on grids of a few workgroups -- runs on the side stream, under the
+                    # video discriminator's GEMMs; autograd replays each node's backward on the stream of its forward, so
+                    # the input-gradient half overlaps the same way.  Same kernels on the same inputs: bit-identical.
+                    main = torch.cuda.current_stream()
+                    side.wait_stream(main)
+                    fake_img.record_stream(side)
+                    with torch.cuda.stream(side):
+                        pi, _ = self.dis_img(fake_img)
+                    pv, _ = self.dis_vid(fake_vid)
+                    main.wait_stream(side)
+                    pi.record_stream(main)
+                else:
+                    pv, _ = self.dis_vid(fake_vid)
+                    pi, _ = self.dis_img(fake_img)
                 loss = bce_with_logits_pair(pv, 1.0, pi, 1.0)
                 if batch_adj:      # the video and the image path: two latent adjoints, one launch
                     self.gen._adjoint_batch = dict(expect=2, ops=[], keep=[])
