@@ -482,3 +482,38 @@ def test_joint_generator_pass_equals_the_two_calls(kind, images_first):
     for n, a, b in zip(names, g0, g1):
         scale = float(a.abs().max()) + 1e-6
         assert float((a - b).abs().max()) <= 1e-3 * scale, (n, float((a - b).abs().max()), scale)   # (4-sample BN batches)
+
+
+def test_sample_pair_falls_back_to_the_two_calls_when_the_rows_do_not_split():
+    """A batch whose statistics rows do not split at the batch boundary (here 3 videos = 48 rows + 3 image rows: no tile
+    boundary at row 48 in the first layers) cannot be decoded jointly: can_pair says so, sample_pair runs the two calls --
+    bit-identical to calling them -- and the trainer's step() keeps working on such a batch size."""
+    def make():
+        seed_all(81)
+        return G.VideoGeneratorMNISTODE(1, 50, 0, 16, 16, ngf=16).cuda()
+    gen = make()
+    if gen.can_pair(3, 3):
+        pytest.skip("this build decodes 48 + 3 rows jointly")
+    outs = []
+    for joint in (True, False):
+        gen = make()
+        seed_all(82)
+        with torch.no_grad():
+            if joint:
+                (v, _), (i, _) = gen.sample_pair(3, 3, images_first=True)
+            else:
+                i, _ = gen.sample_images(3)
+                v, _ = gen.sample_videos(3)
+        outs.append((v.clone(), i.clone(), [b.clone() for b in gen.buffers()]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)
+    seed_all(83)
+    gen, dv, di = G.build_mnist(ngf=8, ndf=8)
+    gen.cuda(); dv.cuda(); di.cuda()
+    tr = G.GanTrainer(gen, dv, di)
+    imgs = [torch.rand(3, 1, 28, 28).cuda() for _ in range(2)]
+    vids = [torch.rand(3, 16, 1, 28, 28).cuda() for _ in range(2)]
+    for _ in range(2):
+        li, lv, lg = tr.step(imgs, vids)
+    assert all(torch.isfinite(x) for x in (li, lv, lg))
