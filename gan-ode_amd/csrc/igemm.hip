@@ -270,7 +270,6 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const IgemmArgs a) {
   }
 }
 
-__device__ __attribute__((aligned(16))) const float gode_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 #define IGEMM_MAX_LIVE_TAPS 64   // MODE 3 tap table (+1 slot read past the end)
 
 // ---------------------------------------------------------------------------------------------------------------
