@@ -1096,6 +1096,24 @@ static void choose_fast(const gode_igemm_op* op, const IgemmGeom& G, int* tile_o
     }
   }
   if (cycles_out) *cycles_out = best;
+  if (live_taps) {
+    // Live-tap launches whose 128x128 grid does not cover the chip (UCF video-D layer 3 input gradient: 224 / 112 tiles): the
+    // tiles of the end planes are a quarter as long as those of the middle planes and all of them are resident at once, so the
+    // launch lasts as long as the CU that drew the long ones -- the estimate above (equal tiles) is 20-30 % off there.  Small
+    // tiles even that out: 4-5 workgroups of 64x64 per CU (scripts/sweep_tiles.py, N = 32 / 16: 371 -> 288 us unsplit, 209 ->
+    // 179 us split 3 ways; every other live-tap shape of the configs keeps the model's choice within 2 %).
+    int64_t t128 = 0, t64 = 0;
+    for (int i = 0; i < G.nphase; ++i) {
+      t128 += (int64_t)gode_ceil_div(G.ph[i].M, 128) * gode_ceil_div(G.Ncols, 128);
+      t64 += (int64_t)gode_ceil_div(G.ph[i].M, 64) * gode_ceil_div(G.Ncols, 64);
+    }
+    if (t128 < 256 && G.Ncols >= 64 && min_slabs == max_slabs) {
+      int k = (int)((1152 + t64 / 2) / t64);
+      if (k < 1) k = 1;
+      while (k > 1 && (min_slabs / k < 8 || out_bytes * k > 192e6)) --k;
+      best_tile = TILE_64x64; best_k = k;
+    }
+  }
   *tile_out = best_tile;
   sp_out->positions = positions;
   sp_out->ksplit = 1; sp_out->slabs_per_split = 0;

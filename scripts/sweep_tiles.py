@@ -30,11 +30,18 @@ cases = [("dec L1 N=512", make_geom(512, 256, 512, (1, 8, 8), (1, 4, 4), (1, 4, 
          ("ucf vidD L1", g3(16, 64, 128, (13, 32, 32), (4, 4, 4), (1, 2, 2), (0, 1, 1))),
          ("ucf vidD L2", g3(16, 128, 256, (10, 16, 16), (4, 4, 4), (1, 2, 2), (0, 1, 1))),
          ("ucf vidD L3", g3(16, 256, 512, (7, 8, 8), (4, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("ucf vidD L3 N=32", g3(32, 256, 512, (7, 8, 8), (4, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("ucf vidD L1 N=32", g3(32, 64, 128, (13, 32, 32), (4, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("ucf vidD L2 N=32", g3(32, 128, 256, (10, 16, 16), (4, 4, 4), (1, 2, 2), (0, 1, 1))),
          ("img convT1 N=32", make_geom(32, 256, 512, (1, 8, 8), (1, 4, 4), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
          ("img convT2 N=32", make_geom(32, 128, 256, (1, 16, 16), (1, 8, 8), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
          ("img convT3 N=32", make_geom(32, 64, 128, (1, 32, 32), (1, 16, 16), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
          ("imgD L1 N=32", make_geom(32, 64, 128, (1, 14, 14), (1, 7, 7), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
          ("imgD L2 N=32", make_geom(32, 128, 256, (1, 7, 7), (1, 3, 3), (1, 4, 4), (1, 2, 2), (0, 1, 1)))]
+import os as _os
+_f = _os.environ.get('GODE_SWEEP_FILTER')
+if _f:
+    cases = [c for c in cases if _f in c[0]]
 for name, g in cases:
     for d, dn in ((L.FPROP, "fprop"), (L.DGRAD, "dgrad")):
         src_dims = (g.N, g.Do, g.Ho, g.Wo, g.Co) if d == L.DGRAD else (g.N, g.Di, g.Hi, g.Wi, g.Ci)
