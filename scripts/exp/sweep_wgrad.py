@@ -17,7 +17,16 @@ cases = [("vidD L1 N=64", g3(64, 64, 128, (15, 15, 15), (2, 2, 2), (1, 2, 2), (0
          ("dec L2 N=512", make_geom(512, 128, 256, (1, 16, 16), (1, 8, 8), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
          ("dec L3 N=512", make_geom(512, 64, 128, (1, 32, 32), (1, 16, 16), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
          ("imgD L1 N=64", make_geom(64, 64, 128, (1, 14, 14), (1, 7, 7), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
-         ("imgD L2 N=64", make_geom(64, 128, 256, (1, 7, 7), (1, 3, 3), (1, 4, 4), (1, 2, 2), (0, 1, 1)))]
+         ("imgD L2 N=64", make_geom(64, 128, 256, (1, 7, 7), (1, 3, 3), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("dec L1 N=544", make_geom(544, 256, 512, (1, 8, 8), (1, 4, 4), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("dec L2 N=544", make_geom(544, 128, 256, (1, 16, 16), (1, 8, 8), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("dec L3 N=544", make_geom(544, 64, 128, (1, 32, 32), (1, 16, 16), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("ucf vidD L1 N=32", g3(32, 64, 128, (13, 32, 32), (4, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("ucf vidD L2 N=32", g3(32, 128, 256, (10, 16, 16), (4, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("ucf vidD L3 N=32", g3(32, 256, 512, (7, 8, 8), (4, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("ucf dec L1 N=272", make_geom(272, 256, 512, (1, 8, 8), (1, 4, 4), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("ucf dec L2 N=272", make_geom(272, 128, 256, (1, 16, 16), (1, 8, 8), (1, 4, 4), (1, 2, 2), (0, 1, 1))),
+         ("ucf dec L3 N=272", make_geom(272, 64, 128, (1, 32, 32), (1, 16, 16), (1, 4, 4), (1, 2, 2), (0, 1, 1)))]
 for name, g in cases:
     x = torch.randn(g.N, g.Di, g.Hi, g.Wi, g.Ci, device="cuda")
     y = torch.randn(g.N, g.Do, g.Ho, g.Wo, g.Co, device="cuda")
