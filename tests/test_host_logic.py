@@ -248,3 +248,36 @@ def test_solver_grid_arrays_reproduce_the_fixed_grid_solver():
             d = rg[1:] - rg[:-1]
             lo, hi = int(gd["bstep_off"][i - 1]), int(gd["bstep_off"][i])
             assert torch.equal(gd["bstep_dt"][lo:hi], d), (h, i)
+
+
+def test_cost_model_and_statistics_layout_queries_are_host_side():
+    """gode_igemm_model_cycles / gode_igemm_stats_segments (what ConvStack(split_images=...) plans with) do no GPU work:
+    the joint 512 + 32-row decoder batch of configs[1] prices above its two parts on the layers whose 512 rows fill whole
+    rounds of 256 workgroups (so the engine launches those GEMMs per part), its statistics rows split at the batch boundary,
+    and an op off the modelled path answers -1."""
+    import ctypes as C
+    from gan_ode_amd.engine import make_geom
+    lib = L.lib()
+
+    def cyc(n, ci, co, hw):
+        g = make_geom(n, ci, co, (1, 2 * hw, 2 * hw), (1, hw, hw), (1, 4, 4), (1, 2, 2), (0, 1, 1))
+        return lib.gode_igemm_model_cycles(C.byref(L.IgemmOp(g=g, dir=L.DGRAD, tile=0))), g
+    for ci, co, hw in ((256, 512, 4), (128, 256, 8)):
+        joint, g = cyc(544, ci, co, hw)
+        a, _ = cyc(512, ci, co, hw)
+        b, _ = cyc(32, ci, co, hw)
+        assert joint > 0 and a > 0 and b > 0
+        assert a + b + 12000.0 < joint, (ci, co, joint, a, b)
+    joint, g = cyc(544, 64, 128, 16)              # 4352 tiles of 128x64: the joint launch is the cheaper one
+    a, _ = cyc(512, 64, 128, 16)
+    b, _ = cyc(32, 64, 128, 16)
+    assert joint < a + b + 12000.0
+    seg = (C.c_int32 * 24)()
+    nseg = lib.gode_igemm_stats_segments(C.byref(L.IgemmOp(g=g, dir=L.DGRAD, tile=0)), 512, seg)
+    assert nseg == 4                              # one {begin, split, end} per stride phase
+    for k in range(nseg):
+        b0, sp, e0 = seg[3 * k], seg[3 * k + 1], seg[3 * k + 2]
+        assert b0 < sp < e0 and (sp - b0) * 32 == (e0 - b0) * 512 * 32 // 544
+    assert lib.gode_igemm_stats_segments(C.byref(L.IgemmOp(g=g, dir=L.DGRAD, tile=0)), 0, seg) < 0
+    thin = make_geom(32, 1, 64, (1, 28, 28), (1, 32, 32), (1, 1, 1), (1, 1, 1), (0, 2, 2))
+    assert lib.gode_igemm_model_cycles(C.byref(L.IgemmOp(g=thin, dir=L.DGRAD, tile=0))) == -1.0
