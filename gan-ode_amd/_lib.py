@@ -52,7 +52,9 @@ class BnFinalizeOp(C.Structure):
 class BnBwdOp(C.Structure):
     _fields_ = [("g", ptr), ("y", ptr), ("M", i64), ("C", i32), ("act", i32), ("gamma", ptr), ("mean", ptr),
                 ("invstd", ptr), ("scale", ptr), ("shift", ptr), ("dgamma", ptr), ("dbeta", ptr), ("work", ptr),
-                ("accumulate", i32), ("eval_mode", i32), ("gin", ptr), ("groups", i32), ("pad2_", i32), ("M0", i64)]
+                ("accumulate", i32), ("eval_mode", i32), ("gin", ptr), ("groups", i32), ("pad2_", i32), ("M0", i64),
+                ("r1_s", ptr), ("r1_w", ptr), ("r1_H", i32), ("r1_W", i32), ("r1_h", i32), ("r1_wd", i32), ("r1_off", i32),
+                ("pad3_", i32)]
     KIND = OP_BN_BWD
 
 

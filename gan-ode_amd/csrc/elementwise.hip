@@ -209,6 +209,14 @@ __device__ __forceinline__ float gz_of(float g, float y, float sc, float sh, int
   return g * gode_act_grad(y * sc + sh, act);
 }
 
+// rank-1 upstream gradient (gode_bn_bwd_op.r1_s): the scalar of row r = (image, h, w), zero outside the crop
+__device__ __forceinline__ float r1_scalar(const gode_bn_bwd_op& a, uint32_t r) {       // (M < 2^31: 32-bit divisions)
+  const uint32_t t = r / (uint32_t)a.r1_W, w = r - t * (uint32_t)a.r1_W;
+  const uint32_t n = t / (uint32_t)a.r1_H, h = t - n * (uint32_t)a.r1_H;
+  const int hh = (int)h - a.r1_off, ww = (int)w - a.r1_off;
+  return ((unsigned)hh < (unsigned)a.r1_h && (unsigned)ww < (unsigned)a.r1_wd) ? a.r1_s[((int64_t)n * a.r1_h + hh) * a.r1_wd + ww] : 0.f;
+}
+
 // partial[blk][2][C] (DOUBLE): sum g_z, sum g_z * xhat   (C % 4 == 0, C/4 <= 256).
 // Both sums cancel heavily (signed gradients), and their error is fed back into every element of g_y, so they are
 // accumulated in fp64 end to end; the kernel stays HBM-bound (2 fp64 FMAs per 8 bytes read).
@@ -246,8 +254,12 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const gode_bn_bwd_op
     const int64_t rend = grp == 0 ? G.M0 : a.M;
     const int64_t r1 = r0 + BNB_ROWS < rend ? r0 + BNB_ROWS : rend;
     const float* gsrc = a.gin ? a.gin : a.g;
+    f32x4 w1 = {0.f, 0.f, 0.f, 0.f};
+    if (a.r1_s) w1 = *reinterpret_cast<const f32x4*>(a.r1_w + c);
     for (int64_t r = r0 + rlane; r < r1; r += rl) {
-      const f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + r * a.C + c);
+      f32x4 g;
+      if (a.r1_s) { const float s = r1_scalar(a, (uint32_t)r); g = w1 * s; }
+      else g = *reinterpret_cast<const f32x4*>(gsrc + r * a.C + c);
       const f32x4 y = *reinterpret_cast<const f32x4*>(a.y + r * a.C + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -323,7 +335,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const gode_bn_bwd_op 
     const int grp = (G.groups == 2 && i >= n4_0) ? 1 : 0;
     const int c = (int)((i * 4) % a.C), cs = grp * a.C + c;
     const float* cf = coef + (int64_t)grp * 3 * a.C;
-    f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + i * 4);
+    f32x4 g;
+    if (a.r1_s) g = *reinterpret_cast<const f32x4*>(a.r1_w + c) * r1_scalar(a, (uint32_t)((i * 4) / a.C));
+    else g = *reinterpret_cast<const f32x4*>(gsrc + i * 4);
     const f32x4 y = *reinterpret_cast<const f32x4*>(a.y + i * 4);
     const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + cs), sh = *reinterpret_cast<const f32x4*>(a.shift + cs);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + cs);
@@ -364,6 +378,8 @@ extern "C" int gode_bn_bwd(const gode_bn_bwd_op* op, void* stream) {
     return 0;
   }
   if (op->C % 4 != 0 || !op->invstd || !op->scale || !op->shift || !op->work) return GODE_E_ARG;
+  if (op->r1_s && (!op->r1_w || op->r1_H <= 0 || op->r1_W <= 0 || op->r1_h <= 0 || op->r1_wd <= 0 || op->r1_off < 0 ||
+                   op->M % ((int64_t)op->r1_H * op->r1_W) != 0 || op->M >= (1ll << 31) || ((uintptr_t)op->r1_w % 16) != 0)) return GODE_E_ARG;
   if (op->groups == 2 && op->M0 == 0 && (op->M % 2 != 0)) return GODE_E_ARG;
   if (op->groups == 2 && (op->M0 < 0 || op->M0 >= op->M)) return GODE_E_ARG;
   const int C4 = op->C / 4, CL = C4 < BNB_CL ? C4 : BNB_CL;

@@ -302,6 +302,17 @@ class ConvStack:
                 for n in (g.N, self.split, g.N - self.split)]
         return min(cost) > 0 and cost[1] + cost[2] + 12000.0 < cost[0]        # (+ ~5 us for the second launch)
 
+    def _rank1_head(self, l, has_tanh):
+        """Is layer l the stack's head AND a 1x1, stride-1 transposed convolution to ONE channel on a centre crop behind a
+        BatchNorm layer (the MNIST generator's output layer)?  Its input gradient is then rank 1 (see _build_bwd)."""
+        if l != self.nl - 1 or l == 0 or not has_tanh:
+            return False
+        s, g = self.specs[l], self.specs[l].geom
+        return (s.fwd_dir == L.DGRAD and not s.has_bn and s.co_perm is None and self.specs[l - 1].has_bn and g.Ci == 1 and
+                g.kd == g.kh == g.kw == 1 and g.sd == g.sh == g.sw == 1 and g.Di == g.Do == 1 and g.pd == 0 and
+                g.ph == g.pw and g.Ho == g.Hi + 2 * g.ph and g.Wo == g.Wi + 2 * g.pw and self.params[l].weight.is_contiguous()
+                and self.params[l].weight.data_ptr() % 16 == 0)
+
     def _half_geom(self, g):
         h = L.ConvGeom(*g.key())
         h.N = g.N // 2
@@ -547,14 +558,21 @@ class ConvStack:
                 ops.append(w)
             # input gradient
             if l > 0 or need_input_grad:
-                if self.wpack_b[l] is None:
-                    self.wpack_b[l] = self._shared_pack(l, rev, lib.gode_pack_size(C.byref(s.geom), rev))
-                bpacks.append((l, rev, L.PackOp(g=s.geom, dir=rev, co_canon=0, w=dptr(p.weight),
-                                                wpack=dptr(self.wpack_b[l]), co_perm=dptr(s.co_perm))))
+                rank1 = self._rank1_head(l, "tanh" in patch)
+                if not rank1:
+                    if self.wpack_b[l] is None:
+                        self.wpack_b[l] = self._shared_pack(l, rev, lib.gode_pack_size(C.byref(s.geom), rev))
+                    bpacks.append((l, rev, L.PackOp(g=s.geom, dir=rev, co_canon=0, w=dptr(p.weight),
+                                                    wpack=dptr(self.wpack_b[l]), co_perm=dptr(s.co_perm))))
                 dst = self.g_in if l == 0 else self.g[l - 1]
                 if l not in self._two_b:
                     self._two_b[l] = bool(self.split) and 0 < l < self.nl - 1 and self._two_launches(s.geom, rev)
-                if self._two_b[l]:        # (split stack: one launch per part, see _two_f)
+                if rank1:
+                    # the head is a 1x1 convolution to one channel: its input gradient is w (x) g -- rank 1 -- and the
+                    # BatchNorm backward below forms it on the fly (gode_bn_bwd_op.r1_s) instead of reading it back: one
+                    # 142-MB tensor less written and two less read per generator backward at configs[1]
+                    pass
+                elif self._two_b[l]:      # (split stack: one launch per part, see _two_f)
                     per_in, per_out = int(np.prod(s.in_dims()[1:])), int(np.prod(s.out_dims()[1:]))
                     for n, img0 in ((self.split, 0), (s.geom.N - self.split, self.split)):
                         ops.append(L.IgemmOp(g=self._part_geom(s.geom, n), dir=rev, act=L.ACT_NONE, epilogue=L.EPI_RAW, tile=0,
@@ -577,6 +595,10 @@ class ConvStack:
                                   scale=dptr(self.scale[l - 1]), shift=dptr(self.shift[l - 1]), accumulate=0,
                                   eval_mode=0 if training else 1, groups=2 if self._G2 else 0,
                                   M0=(M // sp.out_dims()[0]) * self.split if self.split else 0)
+                    if self._rank1_head(l, "tanh" in patch):
+                        g = s.geom           # (FPROP view of the head: Ci = 1 on Hi x Wi  ->  Co channels on Ho x Wo, pad = crop offset)
+                        b.r1_s, b.r1_w = dptr(self.g[l]), dptr(p.weight)
+                        b.r1_H, b.r1_W, b.r1_h, b.r1_wd, b.r1_off = g.Ho, g.Wo, g.Hi, g.Wi, g.ph
                     # (groups == 2: per-group batch statistics ([2][C] arrays) in ONE reduce / finalize / apply triple;
                     # dgamma / dbeta receive both groups' sums in group order)
                     bn_work = max(bn_work, lib.gode_bn_bwd_work_size(M, Cc))

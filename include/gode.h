@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GODE_VERSION 103
+#define GODE_VERSION 104
 
 enum { GODE_OK = 0, GODE_E_ARG = -1, GODE_E_SHAPE = -2, GODE_E_KIND = -3 };
 enum { GODE_ACT_NONE = 0, GODE_ACT_RELU = 1, GODE_ACT_LRELU = 2,              /* LeakyReLU slope is 0.2 */
@@ -176,6 +176,11 @@ typedef struct gode_bn_bwd_op {
    * dgamma / dbeta receive both groups' sums in group order (what the reference's two backward passes add up to). */
   int32_t groups, pad2_;
   int64_t M0;   /* groups == 2: rows of group 0 (0: M / 2) */
+  /* Rank-1 upstream gradient (r1_s != NULL; g is then write-only and gin ignored): the layer feeds a 1x1 convolution to ONE
+   * channel whose output is a centre crop (the MNIST generator's head, models/mocogan.py:151), so g_a[row][c] =
+   * r1_w[c] * r1_s[crop(row)] and the [M][C] gradient tensor need not be written and read back before this op.  Rows are
+   * (image, h, w) over r1_H x r1_W; r1_s is (image, h - r1_off, w - r1_off) over r1_h x r1_w, zero outside. */
+  const float* r1_s; const float* r1_w; int32_t r1_H, r1_W, r1_h, r1_wd, r1_off, pad3_;
 } gode_bn_bwd_op;
 int gode_bn_bwd(const gode_bn_bwd_op* op, void* stream);
 int64_t gode_bn_bwd_work_size(int64_t M, int32_t C);
