@@ -291,6 +291,59 @@ def test_bn_backward_two_groups_in_one_launch_triple_is_bitwise_two_passes(M, Cc
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("groups", [0, 2])
+def test_bn_backward_with_a_rank1_upstream_gradient_is_bitwise_the_materialised_one(groups):
+    """gode_bn_bwd_op.r1_s: the gradient entering the BatchNorm backward is w[c] * s[crop(row)] (the MNIST generator's
+    head is a 1x1 convolution to one channel on the centre 28x28 of the 32x32 map, models/mocogan.py:151).  Formed in
+    registers it must give the bits of the op run on the materialised [M][C] tensor -- also with two BatchNorm batches of
+    unequal size (the joint generator pass)."""
+    gen = torch.Generator().manual_seed(91 + groups)
+    N, H, W, hh, ww, off, Cc = 5, 32, 32, 28, 28, 2, 64
+    M = N * H * W
+    y = (torch.randn(M, Cc, generator=gen) * 2 + 1).cuda()
+    w = torch.randn(Cc, generator=gen).cuda()
+    s = torch.randn(N, hh, ww, generator=gen).cuda()
+    full = torch.zeros(N, H, W, device="cuda")
+    full[:, off:off + hh, off:off + ww] = s
+    ga = (full.reshape(M, 1) * w.reshape(1, Cc)).contiguous()          # one rounding per element, as the head's dgrad kernel
+    gam = (torch.rand(Cc, generator=gen) + 0.5).cuda()
+    ng = 2 if groups == 2 else 1
+    M0 = 3 * H * W if groups == 2 else 0
+    st = {k: torch.empty(ng, Cc, device="cuda") for k in ("mean", "invstd", "scale", "shift")}
+    bounds = [(0, M0), (M0, M)] if groups == 2 else [(0, M)]
+    for grp, (a, b) in enumerate(bounds):
+        yy = y[a:b].double()
+        mean, var = yy.mean(0), yy.var(0, unbiased=False)
+        inv = 1.0 / torch.sqrt(var + 1e-5)
+        st["mean"][grp] = mean.float(); st["invstd"][grp] = inv.float()
+        st["scale"][grp] = (gam.double() * inv).float()
+        st["shift"][grp] = (0.1 - mean * gam.double() * inv).float()
+    lib = L.lib()
+    work = torch.empty(lib.gode_bn_bwd_work_size(M, Cc), device="cuda")
+    outs = []
+    for rank1 in (False, True):
+        g = ga.clone() if not rank1 else torch.full((M, Cc), float("nan"), device="cuda")     # rank 1: g is write-only
+        dg, db = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+        op = L.BnBwdOp(g=g.data_ptr(), y=y.data_ptr(), M=M, C=Cc, act=L.ACT_RELU, gamma=gam.data_ptr(),
+                       mean=st["mean"].data_ptr(), invstd=st["invstd"].data_ptr(), scale=st["scale"].data_ptr(),
+                       shift=st["shift"].data_ptr(), dgamma=dg.data_ptr(), dbeta=db.data_ptr(), work=work.data_ptr(),
+                       accumulate=0, groups=groups, M0=M0)
+        if rank1:
+            op.r1_s, op.r1_w = s.data_ptr(), w.data_ptr()
+            op.r1_H, op.r1_W, op.r1_h, op.r1_wd, op.r1_off = H, W, hh, ww, off
+        L.run_one(op, stream())
+        torch.cuda.synchronize()
+        outs.append((g.clone(), dg.clone(), db.clone()))
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    bad = L.BnBwdOp(g=outs[0][0].data_ptr(), y=y.data_ptr(), M=M, C=Cc, act=L.ACT_RELU, gamma=gam.data_ptr(),
+                    mean=st["mean"].data_ptr(), invstd=st["invstd"].data_ptr(), scale=st["scale"].data_ptr(),
+                    shift=st["shift"].data_ptr(), work=work.data_ptr(), groups=groups, M0=M0, r1_s=s.data_ptr(),
+                    r1_w=w.data_ptr(), r1_H=H, r1_W=W + 1, r1_h=hh, r1_wd=ww, r1_off=off)      # M is not a multiple of H * W
+    with pytest.raises(RuntimeError):
+        L.run_one(bad, stream())
+
+
 def _ode_setup(N, T, seed, prenet=True):
     from oracle.mocogan_ref import OdeRhs
     torch.manual_seed(seed)
