@@ -344,6 +344,42 @@ def test_bn_backward_with_a_rank1_upstream_gradient_is_bitwise_the_materialised_
         L.run_one(bad, stream())
 
 
+def test_batched_weight_packing_brick_kernel_is_bitwise_the_elementwise_map():
+    """Runs of pack ops in a program go through gode_pack_batch_: panels with regular shapes take the LDS brick kernel
+    (pack_tile_kernel), the rest the element-wise one; a single gode_pack_weights call always takes the element-wise map
+    of conv_geom.h.  Same permutation of the same floats: bit-identical panels, for every layer shape of the three configs
+    in both directions (incl. 64 taps = two tap blocks, a 1-channel first layer and the permuted full-K generator input)."""
+    from gan_ode_amd.engine import conv_out, make_geom
+
+    def g3(N, Ci, Co, xi, k, s, p):
+        return make_geom(N, Ci, Co, xi, tuple(conv_out(xi[a], k[a], s[a], p[a]) for a in range(3)), k, s, p)
+    geoms = [make_geom(4, 256, 512, (1, 8, 8), (1, 4, 4), (1, 4, 4), (1, 2, 2), (0, 1, 1)),
+             make_geom(4, 64, 128, (1, 32, 32), (1, 16, 16), (1, 4, 4), (1, 2, 2), (0, 1, 1)),
+             g3(2, 64, 128, (15, 15, 15), (2, 2, 2), (1, 2, 2), (0, 1, 1)),
+             g3(2, 128, 256, (10, 16, 16), (4, 4, 4), (1, 2, 2), (0, 1, 1)),
+             g3(2, 3, 64, (16, 64, 64), (4, 4, 4), (1, 2, 2), (0, 1, 1)),
+             g3(2, 1, 64, (16, 28, 28), (2, 2, 2), (1, 2, 2), (0, 1, 1)),
+             make_geom(4, 48, 80, (1, 8, 8), (1, 4, 4), (1, 4, 4), (1, 2, 2), (0, 1, 1)),
+             make_geom(4, 512, 72, (1, 4, 4), (1, 1, 1), (1, 4, 4), (1, 1, 1), (0, 0, 0))]
+    lib = L.lib()
+    gen = torch.Generator().manual_seed(17)
+    ops, keep, refs = [], [], []
+    for g in geoms:
+        w = torch.randn(g.Co, g.Ci, g.kd, g.kh, g.kw, generator=gen).cuda()
+        for d in (L.FPROP, L.DGRAD):
+            n = lib.gode_pack_size(C.byref(g), d)
+            assert n > 0
+            ref = torch.full((n,), float("nan"), device="cuda")
+            L.check(lib.gode_pack_weights(C.byref(g), d, w.data_ptr(), ref.data_ptr(), None, 0, stream()))
+            out = torch.full((n,), float("nan"), device="cuda")
+            ops.append(L.PackOp(g=g, dir=d, co_canon=0, w=w.data_ptr(), wpack=out.data_ptr(), co_perm=None))
+            keep.append((w, out)); refs.append(ref)
+    L.Program(ops).run(stream())
+    torch.cuda.synchronize()
+    for (w, out), ref, op in zip(keep, refs, ops):
+        assert torch.equal(out, ref), (op.g.key(), op.dir)
+
+
 def _ode_setup(N, T, seed, prenet=True):
     from oracle.mocogan_ref import OdeRhs
     torch.manual_seed(seed)
