@@ -243,6 +243,54 @@ def test_bn_finalize_and_backward(M, Cc):
     assert rel_err((yd * d["scale"] + d["shift"]).cpu(), ref.detach()) < TOL
 
 
+@pytest.mark.parametrize("form", ["segments", "two_arrays"])
+@pytest.mark.parametrize("order", [0, 1])
+def test_bn_finalize_two_batches_of_unequal_size(form, order):
+    """gode_bn_finalize_op with two BatchNorm batches of DIFFERENT size in one launch (the joint generator pass: 512 video
+    rows + 32 image rows): the partial rows of the two batches given as {begin, split, end} segments of one array (one per
+    stride phase) or as two arrays (one GEMM launch per batch); per-batch statistics against torch, the running statistics
+    after BOTH momentum updates in the order the reference made its two forward calls, num_batches_tracked += 2."""
+    gen = torch.Generator().manual_seed(5 + order)
+    Cc, n0, n1, eps, mom = 32, 1536, 96, 1e-5, 0.1
+    ys = [torch.randn(n0, Cc, generator=gen) * 2 + 1, torch.randn(n1, Cc, generator=gen) * 0.5 - 2]
+
+    def partials(y, rows):
+        return torch.stack([torch.stack([c.sum(0), (c * c).sum(0)]) for c in torch.chunk(y, rows)])     # [rows][2][C]
+    gam, bet = (torch.rand(Cc, generator=gen) + 0.5).cuda(), torch.randn(Cc, generator=gen).cuda()
+    rm, rv, nbt = torch.zeros(Cc).cuda(), torch.ones(Cc).cuda(), torch.zeros((), dtype=torch.int64).cuda()
+    d = {k: torch.empty(2, Cc, device="cuda") for k in ("mean", "invstd", "scale", "shift")}
+    op = L.BnFinalizeOp(ncols=Cc, C=Cc, count=n0, count1=n1, gamma=gam.data_ptr(), beta=bet.data_ptr(), running_mean=rm.data_ptr(),
+                        running_var=rv.data_ptr(), num_batches_tracked=nbt.data_ptr(), mean=d["mean"].data_ptr(),
+                        invstd=d["invstd"].data_ptr(), scale=d["scale"].data_ptr(), shift=d["shift"].data_ptr(), momentum=mom,
+                        eps=eps, training=1, groups=2, order=order)
+    if form == "segments":       # two "phases": rows [0,6) = 4 of batch 0 + 2 of batch 1, rows [6,11) = 4 + 1
+        p0, p1 = partials(ys[0], 8), partials(ys[1], 3)
+        allrows = torch.cat([p0[:4], p1[:2], p0[4:], p1[2:]])
+        stats = allrows.permute(1, 2, 0).contiguous().cuda()              # the ABI layout [2][C][rows]
+        op.stats, op.rows, op.nseg = stats.data_ptr(), 11, 2
+        for k, v in enumerate((0, 4, 6, 6, 10, 11)):
+            op.seg[k] = v
+    else:
+        s0 = partials(ys[0], 5).permute(1, 2, 0).contiguous().cuda()
+        s1 = partials(ys[1], 2).permute(1, 2, 0).contiguous().cuda()
+        op.stats, op.rows, op.stats1, op.rows1 = s0.data_ptr(), 5, s1.data_ptr(), 2
+    L.run_one(op, stream())
+    torch.cuda.synchronize()
+    bn = torch.nn.BatchNorm1d(Cc, eps=eps, momentum=mom)
+    with torch.no_grad():
+        bn.weight.copy_(gam.cpu()); bn.bias.copy_(bet.cpu())
+    for grp in ((1, 0) if order else (0, 1)):
+        bn(ys[grp])                                                       # the reference's two forward calls, in its order
+    assert rel_err(rm.cpu(), bn.running_mean) < 1e-5 and rel_err(rv.cpu(), bn.running_var) < 1e-5 and int(nbt) == 2
+    for grp in range(2):
+        yy = ys[grp].double()
+        mean, inv = yy.mean(0), 1.0 / torch.sqrt(yy.var(0, unbiased=False) + eps)
+        assert rel_err(d["mean"][grp].cpu(), mean.float()) < 1e-5 and rel_err(d["invstd"][grp].cpu(), inv.float()) < 1e-5
+        sc = gam.cpu().double() * inv
+        assert rel_err(d["scale"][grp].cpu(), sc.float()) < 1e-5
+        assert rel_err(d["shift"][grp].cpu(), (bet.cpu().double() - mean * sc).float()) < 1e-5
+
+
 @pytest.mark.parametrize("M,Cc", [(2 * 700, 64), (2 * 257, 8), (2 * 4096, 256)])
 def test_bn_backward_two_groups_in_one_launch_triple_is_bitwise_two_passes(M, Cc):
     """gode_bn_bwd_op.groups == 2 (the paired discriminator pass): rows [0, M/2) and [M/2, M) with their own batch
