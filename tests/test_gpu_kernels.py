@@ -428,6 +428,54 @@ def test_batched_weight_packing_brick_kernel_is_bitwise_the_elementwise_map():
         assert torch.equal(out, ref), (op.g.key(), op.dir)
 
 
+def test_operands_beyond_2_gib_take_the_register_staged_kernels():
+    """The LDS-DMA GEMM loops address their operands as raw buffers (32-bit byte offsets); an operand of 2 GiB or more makes
+    gode_igemm / gode_wgrad fall back to the register-staged kernels.  Conv2d 64 -> 64 k3 p1 on 8,200 images of 32x32
+    (2.0 GiB in, 2.0 GiB out): the first and the last images against the same op on those images alone (small tensors: the
+    DMA kernels), and the weight gradient against the sum of the weight gradients of two halves."""
+    lib = L.lib()
+    N, Cc, HW = 8200, 64, 32
+    g = make_geom(N, Cc, Cc, (1, HW, HW), (1, HW, HW), (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(N, 1, HW, HW, Cc, device="cuda", generator=gen)
+    assert x.numel() * 4 >= 2 ** 31
+    w = torch.randn(Cc, Cc, 1, 3, 3, device="cuda", generator=gen) * 0.05
+    wp = torch.empty(lib.gode_pack_size(C.byref(g), L.FPROP), device="cuda")
+    L.check(lib.gode_pack_weights(C.byref(g), L.FPROP, w.data_ptr(), wp.data_ptr(), None, 0, stream()))
+
+    def conv(geom, src):
+        out = torch.empty(geom.N, 1, HW, HW, Cc, device="cuda")
+        op = L.IgemmOp(g=geom, dir=L.FPROP, act=L.ACT_NONE, epilogue=L.EPI_RAW, tile=0, src=src.data_ptr(), wpack=wp.data_ptr(),
+                       out=out.data_ptr())
+        ws = lib.gode_igemm_work_size(C.byref(op))
+        work = torch.empty(max(ws, 1), device="cuda")
+        op.work = work.data_ptr()
+        L.run_one(op, stream())
+        torch.cuda.synchronize()
+        return out
+    big = conv(g, x)
+    g8 = make_geom(8, Cc, Cc, (1, HW, HW), (1, HW, HW), (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    for a in (0, N - 8):
+        small = conv(g8, x[a:a + 8].contiguous())
+        assert float((big[a:a + 8] - small).abs().max()) <= 1e-5 * float(small.abs().max())
+    # weight gradient: x beyond 2 GiB -> register-staged kernel; halves (1 GiB each) -> DMA kernel
+    y = torch.randn(N, 1, HW, HW, Cc, device="cuda", generator=gen) * 0.1
+
+    def wgrad(geom, xs, ys):
+        dw = torch.empty(Cc, Cc, 1, 3, 3, device="cuda")
+        op = L.WgradOp(g=geom, act=L.ACT_NONE, xform_on_y=0, splits=0, accumulate=0, x=xs.data_ptr(), y=ys.data_ptr(), dw=dw.data_ptr())
+        work = torch.empty(lib.gode_wgrad_work_size(C.byref(op)), device="cuda")
+        op.work = work.data_ptr()
+        L.run_one(op, stream())
+        torch.cuda.synchronize()
+        return dw
+    whole = wgrad(g, x, y)
+    h = N // 2
+    gh = make_geom(h, Cc, Cc, (1, HW, HW), (1, HW, HW), (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    halves = wgrad(gh, x[:h], y[:h]) + wgrad(gh, x[h:], y[h:])
+    assert float((whole - halves).abs().max()) <= 2e-5 * float(halves.abs().max())
+
+
 def _ode_setup(N, T, seed, prenet=True):
     from oracle.mocogan_ref import OdeRhs
     torch.manual_seed(seed)
