@@ -391,6 +391,44 @@ def test_reference_api_corner_cases():
     assert rel_err(out.cpu(), want) < TOL
 
 
+@pytest.mark.parametrize("B", [1, 2, 5])
+def test_smallest_and_odd_batches_against_oracle(B):
+    """Batch 1 (a single clip: the BatchNorm batches are its 16 frames / one image, the squeezed discriminator outputs lose
+    the batch dimension, models/mocogan.py:162), 2 and an odd 5: sample_videos / sample_images frames at 1e-4 against the
+    oracle on the same seeds, and one full training iteration (the joint generator pass falls back to the two calls where
+    the rows do not split) with its three losses at 1e-4."""
+    seed_all(61 + B)
+    gen, dv, di = G.build_mnist(ngf=16, ndf=16)
+    ogen, odv, odi = M.build_mnist(ngf=16, ndf=16)
+    for m, o in zip((gen, dv, di), (ogen, odv, odi)):
+        o.load_state_dict(m.state_dict())
+    gen.cuda(); dv.cuda(); di.cuda()
+    seed_all(70)
+    vid, _ = gen.sample_videos(B)
+    img, _ = gen.sample_images(B)
+    seed_all(70)
+    rvid, _ = ogen.sample_videos(B)
+    rimg, _ = ogen.sample_images(B)
+    assert vid.shape == rvid.shape == (B, 1, 16, 28, 28) and img.shape == rimg.shape == (B, 1, 28, 28)
+    assert rel_err(vid.detach().cpu(), rvid.detach()) < TOL and rel_err(img.detach().cpu(), rimg.detach()) < TOL
+    # (the two sampling calls above moved the BatchNorm running statistics of both generators alike)
+    tr = G.GanTrainer(gen, dv, di)
+    opts = M.make_optimizers(ogen, odv, odi)
+    g = torch.Generator().manual_seed(6)
+    imgs = [torch.rand(B, 1, 28, 28, generator=g) for _ in range(2)]
+    vids = [torch.rand(B, 16, 1, 28, 28, generator=g) for _ in range(2)]
+    seed_all(71)
+    got = [float(v) for v in G.train_step(tr, [t.cuda() for t in imgs], [t.cuda() for t in vids])]
+    seed_all(71)
+    want = [float(v) for v in M.train_step(ogen, odv, odi, opts, imgs, vids)]
+    assert np.allclose(got, want, rtol=1e-4, atol=0), (got, want)
+    for (k, v), (_, w) in zip(gen.state_dict().items(), ogen.state_dict().items()):
+        if "running_" in k:
+            assert rel_err(v.cpu(), w) < 1e-4, k
+        elif v.dtype == torch.int64:
+            assert int(v) == int(w), k
+
+
 def test_full_width_train_iterations_batch8_against_oracle():
     """BASELINE.json configs[0] (the reference's CPU-runnable case: batch 8, 16x1x28x28, ngf=ndf=64, rk4): two full
     training iterations (2 x [image-D, video-D] + G each) with FusedAdam / fused BCE against the oracle's
