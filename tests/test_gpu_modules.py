@@ -391,15 +391,17 @@ def test_reference_api_corner_cases():
     assert rel_err(out.cpu(), want) < TOL
 
 
-@pytest.mark.parametrize("B", [1, 2, 5])
-def test_smallest_and_odd_batches_against_oracle(B):
+@pytest.mark.parametrize("B,rnn", [(1, False), (2, False), (5, False), (1, True), (5, True)])
+def test_smallest_and_odd_batches_against_oracle(B, rnn):
     """Batch 1 (a single clip: the BatchNorm batches are its 16 frames / one image, the squeezed discriminator outputs lose
     the batch dimension, models/mocogan.py:162), 2 and an odd 5: sample_videos / sample_images frames at 1e-4 against the
     oracle on the same seeds, and one full training iteration (the joint generator pass falls back to the two calls where
     the rows do not split) with its three losses at 1e-4."""
     seed_all(61 + B)
     gen, dv, di = G.build_mnist(ngf=16, ndf=16)
-    ogen, odv, odi = M.build_mnist(ngf=16, ndf=16)
+    ogen, odv, odi = (M.build_mnist_odernn if rnn else M.build_mnist)(ngf=16, ndf=16)
+    if rnn:      # (the ODE-RNN generator: adaptive solves with the error norm over the whole -- here tiny -- batch)
+        gen = G.VideoGeneratorMNISTODERNN(1, 50, 0, 16, 16, ngf=16)
     for m, o in zip((gen, dv, di), (ogen, odv, odi)):
         o.load_state_dict(m.state_dict())
     gen.cuda(); dv.cuda(); di.cuda()
