@@ -771,6 +771,13 @@ __global__ void __launch_bounds__(256) wgrad_reduce_small_kernel(const float* wo
 // a 0.6-GFLOP problem (image-D layer 2) loses 15 %, hence the size floor.
 static int wg_tile(const gode_conv_geom& g) {
   const int64_t macs = (int64_t)g.N * g.Do * g.Ho * g.Wo * g.Co * g.Ci * g.kd * g.kh * g.kw;
+  static const char* tenv = getenv("GODE_WGRAD_TILE");       // tuning knob (scripts/exp/sweep_wgrad.py): 2 = 128x128, 3 = 256x128, 4 = 128x256
+  if (tenv) {
+    const int t = atoi(tenv);
+    if (t == 2 && g.Co > 64) return 2;
+    if (t == 3 && g.Co % 256 == 0 && g.Ci % 4 == 0) return 3;
+    if (t == 4 && g.Co % 128 == 0 && g.Ci % 4 == 0 && (g.kd * g.kh * g.kw * g.Ci) % 256 == 0) return 4;
+  }
   if (g.Co % 256 == 0 && g.Ci % 4 == 0 && macs >= (1ll << 31)) return 3;
   // 128 x 256, 8 waves: the decoder's last stride-2 layer (326 -> 321 us); with only two column tiles (MNIST video-D
   // layer 1, Kt = 512) it needs 128 position splits and loses 12 %
