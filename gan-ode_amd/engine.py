@@ -84,13 +84,20 @@ class ConvStack:
 
     def __init__(self, specs: Sequence[LayerSpec], params: Sequence[LayerParams], device, owns_input: bool,
                  momentum=0.1, eps=1e-5, pack_cache: Optional[dict] = None, groups: int = 1, split_images: int = 0,
-                 split_order: int = 0):
+                 split_order: int = 0, two_lane_backward: bool = False):
         """groups == 2: ONE pass over two image groups [first source; second source] (a discriminator applied to real
         and fake in the same launches, specs built for the joint batch): every BatchNorm keeps per-group batch
         statistics -- exactly what the reference's two forward calls compute -- while the GEMMs, weight gradients and
         elementwise passes run once over twice the rows.  Conv (FPROP) stacks with caller-owned inputs only."""
         self.specs, self.params, self.device = list(specs), list(params), device
         self.groups = groups
+        # two_lane_backward: the weight gradients of a backward pass run on a second stream next to the input-gradient /
+        # BatchNorm-backward chain: wgrad(l) only reads what the chain has finished (g[l]) and nothing reads what it writes,
+        # so each run of weight-gradient ops waits for ONE event on the chain's stream and the streams join at the end.
+        # Same kernels on the same inputs: bit-identical.  For stacks whose GEMM grids leave workgroup slots idle (the
+        # discriminators at the configs' batch sizes).
+        self.two_lane = bool(two_lane_backward)
+        self._lane_stream = None
         # split_images > 0 (plan-owned input only): the batch is [first split_images images; the rest] -- two BatchNorm
         # batches of DIFFERENT size decoded in one pass (the generator's video and image paths: the reference calls `main`
         # on each, models/mocogan.py:276,293): per-part batch statistics, every GEMM / elementwise launch once over all
@@ -618,7 +625,45 @@ class ConvStack:
                 b.work = bn_buf.data_ptr()
         patch["packs"] = bpacks
         self._attach_work([op for op in ops if isinstance(op, L.IgemmOp)])
+        if self.two_lane and need_param_grad:
+            # maximal runs of weight-gradient ops ("W") and of everything else ("C", the chain): a W run depends on the C ops
+            # before it, no C op depends on a W op
+            segs, run, kind = [], [], None
+            for op in ops:
+                k = "W" if isinstance(op, L.WgradOp) else "C"
+                if k != kind and run:
+                    segs.append((kind, L.Program(run)))
+                    run = []
+                kind = k
+                run.append(op)
+            if run:
+                segs.append((kind, L.Program(run)))
+            if sum(1 for k, _ in segs if k == "W") > 0 and sum(1 for k, _ in segs if k == "C") > 0:
+                patch["segments"] = segs
         return L.Program(ops), patch
+
+    def _run_backward(self, prog, patch):
+        """One backward program on the current stream -- or (two_lane_backward) its runs of weight-gradient ops on the lane
+        stream, each behind an event that says the chain has produced what they read, joined before returning.  Not inside a
+        stream capture: hipStreamEndCapture of ROCm 7.2 crashes on this fork pattern (several event edges into one forked
+        stream from a stream that is itself a fork); a captured graph keeps the single-lane order."""
+        segs = patch.get("segments")
+        if segs is None or L.TRACE is not None or torch.cuda.is_current_stream_capturing():
+            prog.run(stream_ptr())
+            return
+        main = torch.cuda.current_stream()
+        if self._lane_stream is None or self._lane_stream.device != main.device:
+            self._lane_stream = torch.cuda.Stream(device=main.device)
+        side = self._lane_stream
+        for kind, seg in segs:
+            if kind == "C":
+                seg.run(main.cuda_stream)
+                continue
+            ev = torch.cuda.Event()          # (a fresh event per dependency)
+            ev.record(main)
+            side.wait_event(ev)
+            seg.run(side.cuda_stream)
+        main.wait_stream(side)
 
     def _patch_user_input(self, patch):
         if self.x_in is None and "wgrad0" in patch:
@@ -673,7 +718,7 @@ class ConvStack:
                 b.dbeta = per[l][2].data_ptr()
                 b.accumulate = 1 if (per[l][3] or force) else 0
             self._patch_user_input(patch)
-            prog.run(stream_ptr())
+            self._run_backward(prog, patch)
             self.busy = False
             return None, None, (self.g_in if need_input_grad else None)
         flat = torch.empty(self.n_grad_floats(), dtype=torch.float32, device=self.device)

@@ -1256,6 +1256,10 @@ class _DiscPairFn(torch.autograd.Function):
 
 
 class _DiscBase(nn.Module):
+    # ConvStack(two_lane_backward=...): the weight gradients of a backward pass on a second stream next to the input-gradient
+    # chain.  UCF iteration 16.83 -> 16.53 ms, MNIST / ODE-RNN -0.3 / -0.5 % (same box, same run).
+    two_lane_backward = True
+
     _gode_direct_grads = True
 
     def _specs(self, x_shape):
@@ -1298,7 +1302,7 @@ class _DiscBase(nn.Module):
         key = tuple(x.shape)
         plan = self._pool.get(key, lambda: ConvStack(self._specs(x.shape), self._layer_params(),
                                                      self.main[1].weight.device, owns_input=False,
-                                                     pack_cache=self._pool.pack_cache))
+                                                     pack_cache=self._pool.pack_cache, two_lane_backward=self.two_lane_backward))
         params = []
         for p in self._layer_params():
             params.append(p.weight)
@@ -1337,7 +1341,8 @@ class _DiscBase(nn.Module):
         key = ("pair",) + tuple(first.shape)
         plan = self._pool.get(key, lambda: ConvStack(self._specs(joint_shape), self._layer_params(),
                                                      self.main[1].weight.device, owns_input=False,
-                                                     pack_cache=self._pool.pack_cache, groups=2))
+                                                     pack_cache=self._pool.pack_cache, groups=2,
+                                                     two_lane_backward=self.two_lane_backward))
         params = []
         for p in self._layer_params():
             params.append(p.weight)
