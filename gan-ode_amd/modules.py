@@ -168,7 +168,7 @@ class _GenPlan:
         self.dt = (tt[1:] - tt[:-1]).to(dev) if T > 1 else torch.zeros(1, **f32)
         if zbuf is None:
             self.stack = ConvStack(gen._decoder_specs(self.rows), gen._decoder_params(), dev, owns_input=True,
-                                   pack_cache=gen._pool.pack_cache)
+                                   pack_cache=gen._pool.pack_cache, two_lane_backward=True)
         else:
             self.stack, self._zbuf = None, zbuf
         self.ode_work = torch.empty(L.lib().gode_ode_bwd_work_size(n_traj), **f32)
@@ -373,7 +373,8 @@ class _GenJointPlan:
         self.gen, self.nv, self.ni, self.T, self.device = gen, nv, ni, T, dev
         self.rows_v, self.rows_i = nv * T, ni
         self.stack = ConvStack(gen._decoder_specs(self.rows_v + self.rows_i), gen._decoder_params(), dev, owns_input=True,
-                               pack_cache=gen._pool.pack_cache, split_images=self.rows_v, split_order=1 if images_first else 0)
+                               pack_cache=gen._pool.pack_cache, split_images=self.rows_v, split_order=1 if images_first else 0,
+                               two_lane_backward=True)       # (UCF G step 4.43 -> 4.34 ms, MNIST neutral)
         self.vid = gen._plan_cls(gen, nv, T, False, zbuf=self.stack.x_in[:self.rows_v])
         self.img = gen._plan_cls(gen, ni, T, True, zbuf=self.stack.x_in[self.rows_v:])
         self.images_first = images_first
