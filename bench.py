@@ -151,7 +151,11 @@ def _kernel_roofline(gen, reps=30, live_traffic=False):
         ms = e0.elapsed_time(e1) / reps
         flop = 2.0 * macs * rows
         per_layer.append(dict(layer=name, ms=ms, gflop=flop / 1e9, tflops=flop / ms / 1e9))
-    dom = max(per_layer[1:4], key=lambda d: d["ms"])
+    # the dominant kernel: the longest launch of the three 34-GFLOP layers.  Since round 3 they are within ~2 % of each other
+    # (263-270 us); among those within 2 % of the longest the LAST layer is reported (the one with the most HBM traffic, and the
+    # one every earlier round reported), so that the line does not flip between kernels from run to run
+    longest = max(d["ms"] for d in per_layer[1:4])
+    dom = [d for d in per_layer[1:4] if d["ms"] >= 0.98 * longest][-1]
     traffic, traffic_src = (None, None)
     if live_traffic:
         traffic, traffic_src = _live_pmc_traffic(per_layer.index(dom))
