@@ -103,7 +103,7 @@ class BnApplyOp(C.Structure):
 
 
 class Col2imOp(C.Structure):
-    _fields_ = [("cols", ptr), ("out", ptr)] + [(n, i32) for n in "N Hi Wi Ho Wo C kh kw sh sw ph pw epilogue pad_".split()]
+    _fields_ = [("cols", ptr), ("out", ptr)] + [(n, i32) for n in "N Hi Wi Ho Wo C kh kw sh sw ph pw epilogue pad_ Di Do kd sd pd pad2_".split()]
     KIND = OP_COL2IM
 
 

@@ -179,12 +179,47 @@ __global__ void __launch_bounds__(256) col2im_rows_kernel(const gode_col2im_op a
   }
 }
 
+// 3-D form: one thread per output voxel, <= ceil(kd/sd) * ceil(kh/sh) * ceil(kw/sw) taps of C floats each, fixed tap order
+__global__ void __launch_bounds__(256) col2im3d_kernel(const gode_col2im_op a) {
+  const int64_t total = (int64_t)a.N * a.Do * a.Ho * a.Wo;
+  const int KC = a.kd * a.kh * a.kw * a.C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ow = (int)(i % a.Wo); int64_t t = i / a.Wo;
+    const int oh = (int)(t % a.Ho); t /= a.Ho;
+    const int od = (int)(t % a.Do), n = (int)(t / a.Do);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int kd = (od + a.pd) % a.sd; kd < a.kd; kd += a.sd) {
+      const int id = (od + a.pd - kd) / a.sd;
+      if (od + a.pd - kd < 0 || id >= a.Di) continue;
+      for (int kh = (oh + a.ph) % a.sh; kh < a.kh; kh += a.sh) {
+        const int ih = (oh + a.ph - kh) / a.sh;
+        if (oh + a.ph - kh < 0 || ih >= a.Hi) continue;
+        for (int kw = (ow + a.pw) % a.sw; kw < a.kw; kw += a.sw) {
+          const int iw = (ow + a.pw - kw) / a.sw;
+          if (ow + a.pw - kw < 0 || iw >= a.Wi) continue;
+          const float* src = a.cols + ((((int64_t)n * a.Di + id) * a.Hi + ih) * a.Wi + iw) * KC + ((kd * a.kh + kh) * a.kw + kw) * a.C;
+          for (int c = 0; c < a.C; ++c) acc[c] += src[c];
+        }
+      }
+    }
+    float* dst = a.out + i * a.C;
+    for (int c = 0; c < a.C; ++c) dst[c] = a.epilogue == GODE_EPI_TANH ? tanhf(acc[c]) : acc[c];
+  }
+}
+
 extern "C" int gode_col2im(const gode_col2im_op* op, void* stream) {
   if (!op || !op->cols || !op->out || op->N <= 0 || op->C <= 0 || op->C > 4 || op->kh <= 0 || op->kw <= 0 || op->sh <= 0 ||
       op->sw <= 0 || op->ph < 0 || op->pw < 0 || op->Hi <= 0 || op->Wi <= 0)
     return GODE_E_ARG;
   if (op->Ho != (op->Hi - 1) * op->sh - 2 * op->ph + op->kh || op->Wo != (op->Wi - 1) * op->sw - 2 * op->pw + op->kw) return GODE_E_SHAPE;
   if (op->epilogue != GODE_EPI_RAW && op->epilogue != GODE_EPI_TANH) return GODE_E_ARG;
+  if (op->kd > 0) {
+    if (op->sd <= 0 || op->pd < 0 || op->Di <= 0 || op->Do != (op->Di - 1) * op->sd - 2 * op->pd + op->kd) return GODE_E_SHAPE;
+    int64_t nb = ((int64_t)op->N * op->Do * op->Ho * op->Wo + 255) / 256; if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(col2im3d_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, *op);
+    GODE_LAUNCH_CHECK();
+    return 0;
+  }
   const int KC = op->kh * op->kw * op->C, R = (op->kh + op->sh - 1) / op->sh;
   const int nq = (op->Ho - 1 + op->ph) / op->sh + 1;             // row groups that contain an output row
   const int64_t lds = (int64_t)R * op->Wi * KC * sizeof(float);

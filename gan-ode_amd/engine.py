@@ -254,6 +254,21 @@ class ConvStack:
             return None
         return make_geom(pixels, g.Ci, g.Co, (1, g.kh, g.kw), (1, 1, 1), (1, g.kh, g.kw), (1, 1, 1), (0, 0, 0))
 
+    def _tail_as_gemm(self):
+        """The input gradient of a thin-INPUT first layer with many taps (<= 4 input channels, >= 64 weight columns per output
+        channel, many positions: the UCF video discriminator's Conv3d(3, 64, 4, ...)) as ONE plain GEMM over the layer's
+        output positions + an overlap-add (gode_col2im, 3-D form): every gradient value is read once instead of once per
+        tap of every input voxel it touches.  Returns the GEMM's geometry or None."""
+        s = self.specs[0]
+        g = s.geom
+        taps = g.kd * g.kh * g.kw
+        pos = g.N * g.Do * g.Ho * g.Wo
+        if (self.groups != 1 or s.fwd_dir != L.FPROP or g.Ci > 4 or taps * g.Ci < 64 or g.Co % 32 != 0 or pos < 16384 or
+                g.Di != (g.Do - 1) * g.sd - 2 * g.pd + g.kd or g.Hi != (g.Ho - 1) * g.sh - 2 * g.ph + g.kh or
+                g.Wi != (g.Wo - 1) * g.sw - 2 * g.pw + g.kw):
+            return None
+        return make_geom(pos, g.Ci, g.Co, (g.kd, g.kh, g.kw), (1, 1, 1), (g.kd, g.kh, g.kw), (1, 1, 1), (0, 0, 0))
+
     def _in_src(self, l):
         """Tensor the consumer layer l reads (activated copy if materialised, else the raw producer output)."""
         if l == 0:
@@ -566,33 +581,49 @@ class ConvStack:
             # input gradient
             if l > 0 or need_input_grad:
                 rank1 = self._rank1_head(l, "tanh" in patch)
-                if not rank1:
-                    if self.wpack_b[l] is None:
-                        self.wpack_b[l] = self._shared_pack(l, rev, lib.gode_pack_size(C.byref(s.geom), rev))
-                    bpacks.append((l, rev, L.PackOp(g=s.geom, dir=rev, co_canon=0, w=dptr(p.weight),
-                                                    wpack=dptr(self.wpack_b[l]), co_perm=dptr(s.co_perm))))
+                tg = self._tail_as_gemm() if l == 0 else None
                 dst = self.g_in if l == 0 else self.g[l - 1]
-                if l not in self._two_b:
-                    self._two_b[l] = bool(self.split) and 0 < l < self.nl - 1 and self._two_launches(s.geom, rev)
-                if rank1:
+                if tg is not None:
+                    # thin-input first layer: one GEMM over its output positions + a 3-D overlap-add (see _tail_as_gemm)
+                    g = s.geom
+                    wp = self._shared_pack(0, "tail_gemm", lib.gode_pack_size(C.byref(tg), L.DGRAD))
+                    bpacks.append((0, "tail_gemm", L.PackOp(g=tg, dir=L.DGRAD, co_canon=0, w=dptr(p.weight), wpack=dptr(wp),
+                                                            co_perm=dptr(s.co_perm))))
+                    if getattr(self, "_tail_cols", None) is None:
+                        self._tail_cols = torch.empty(tg.N * g.kd * g.kh * g.kw * g.Ci, **f32)
+                    ops.append(L.IgemmOp(g=tg, dir=L.DGRAD, act=L.ACT_NONE, epilogue=L.EPI_RAW, tile=0, src=dptr(self.g[0]),
+                                         wpack=dptr(wp), out=dptr(self._tail_cols)))
+                    c2i = L.Col2imOp(cols=dptr(self._tail_cols), out=None, N=g.N, Hi=g.Ho, Wi=g.Wo, Ho=g.Hi, Wo=g.Wi, C=g.Ci,
+                                     kh=g.kh, kw=g.kw, sh=g.sh, sw=g.sw, ph=g.ph, pw=g.pw, epilogue=L.EPI_RAW,
+                                     Di=g.Do, Do=g.Di, kd=g.kd, sd=g.sd, pd=g.pd)
+                    ops.append(c2i)
+                    patch["dgrad0"] = c2i               # (its output, the input gradient, is allocated per call)
+                elif rank1:
                     # the head is a 1x1 convolution to one channel: its input gradient is w (x) g -- rank 1 -- and the
                     # BatchNorm backward below forms it on the fly (gode_bn_bwd_op.r1_s) instead of reading it back: one
                     # 142-MB tensor less written and two less read per generator backward at configs[1]
                     pass
-                elif self._two_b[l]:      # (split stack: one launch per part, see _two_f)
-                    per_in, per_out = int(np.prod(s.in_dims()[1:])), int(np.prod(s.out_dims()[1:]))
-                    for n, img0 in ((self.split, 0), (s.geom.N - self.split, self.split)):
-                        ops.append(L.IgemmOp(g=self._part_geom(s.geom, n), dir=rev, act=L.ACT_NONE, epilogue=L.EPI_RAW, tile=0,
-                                             src=self.g[l].data_ptr() + 4 * img0 * per_out, wpack=dptr(self.wpack_b[l]),
-                                             out=dst.data_ptr() + 4 * img0 * per_in))
                 else:
-                    ig = L.IgemmOp(g=s.geom, dir=rev, act=L.ACT_NONE, epilogue=L.EPI_RAW, tile=0, src=dptr(self.g[l]),
-                                   wpack=dptr(self.wpack_b[l]), out=dptr(dst))
-                    if l == self.nl - 1 and "tanh" not in patch:
-                        readers.append((ig, "src"))
-                    if l == 0:
-                        patch["dgrad0"] = ig        # its output (the input gradient) is allocated per call
-                    ops.append(ig)
+                    if self.wpack_b[l] is None:
+                        self.wpack_b[l] = self._shared_pack(l, rev, lib.gode_pack_size(C.byref(s.geom), rev))
+                    bpacks.append((l, rev, L.PackOp(g=s.geom, dir=rev, co_canon=0, w=dptr(p.weight),
+                                                    wpack=dptr(self.wpack_b[l]), co_perm=dptr(s.co_perm))))
+                    if l not in self._two_b:
+                        self._two_b[l] = bool(self.split) and 0 < l < self.nl - 1 and self._two_launches(s.geom, rev)
+                    if self._two_b[l]:        # (split stack: one launch per part, see _two_f)
+                        per_in, per_out = int(np.prod(s.in_dims()[1:])), int(np.prod(s.out_dims()[1:]))
+                        for n, img0 in ((self.split, 0), (s.geom.N - self.split, self.split)):
+                            ops.append(L.IgemmOp(g=self._part_geom(s.geom, n), dir=rev, act=L.ACT_NONE, epilogue=L.EPI_RAW,
+                                                 tile=0, src=self.g[l].data_ptr() + 4 * img0 * per_out,
+                                                 wpack=dptr(self.wpack_b[l]), out=dst.data_ptr() + 4 * img0 * per_in))
+                    else:
+                        ig = L.IgemmOp(g=s.geom, dir=rev, act=L.ACT_NONE, epilogue=L.EPI_RAW, tile=0, src=dptr(self.g[l]),
+                                       wpack=dptr(self.wpack_b[l]), out=dptr(dst))
+                        if l == self.nl - 1 and "tanh" not in patch:
+                            readers.append((ig, "src"))
+                        if l == 0:
+                            patch["dgrad0"] = ig        # its output (the input gradient) is allocated per call
+                        ops.append(ig)
             if l > 0:
                 sp, pp = self.specs[l - 1], self.params[l - 1]
                 M, Cc = self._count(l - 1), sp.out_dims()[4]

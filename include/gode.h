@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GODE_VERSION 104
+#define GODE_VERSION 105
 
 enum { GODE_OK = 0, GODE_E_ARG = -1, GODE_E_SHAPE = -2, GODE_E_KIND = -3 };
 enum { GODE_ACT_NONE = 0, GODE_ACT_RELU = 1, GODE_ACT_LRELU = 2,              /* LeakyReLU slope is 0.2 */
@@ -154,6 +154,11 @@ typedef struct gode_col2im_op {
   const float* cols; float* out;
   int32_t N, Hi, Wi, Ho, Wo, C, kh, kw, sh, sw, ph, pw;   /* Hi x Wi: the pixels of cols; Ho x Wo: out */
   int32_t epilogue, pad_;                                  /* GODE_EPI_RAW / GODE_EPI_TANH */
+  /* 3-D form (kd > 0; all zero: the 2-D op above): cols pixels are (n, id, ih, iw) over Di x Hi x Wi with kd*kh*kw*C values
+   * each (tap order kd, kh, kw), out is Do x Ho x Wo, od = id*sd - pd + kd.  The input gradient of a thin-INPUT Conv3d (the UCF
+   * video discriminator's first layer, models/mocogan.py:100: 3 channels, 4x4x4 taps) is one GEMM over its output positions
+   * + this overlap-add, instead of a gather of 1,024 values per input voxel. */
+  int32_t Di, Do, kd, sd, pd, pad2_;
 } gode_col2im_op;
 int gode_col2im(const gode_col2im_op* op, void* stream);
 

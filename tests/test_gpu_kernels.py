@@ -476,6 +476,49 @@ def test_operands_beyond_2_gib_take_the_register_staged_kernels():
     assert float((whole - halves).abs().max()) <= 2e-5 * float(halves.abs().max())
 
 
+@pytest.mark.parametrize("shape", [((6, 10, 10), (4, 4, 4), (1, 2, 2), (0, 1, 1)), ((5, 9, 9), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+                                   ((1, 12, 12), (1, 4, 4), (1, 2, 2), (0, 1, 1))])
+def test_thin_input_conv_input_gradient_as_pixel_gemm_plus_3d_col2im(shape):
+    """The input gradient of a convolution with <= 4 input channels as ONE GEMM over its output positions (gode_igemm, DGRAD
+    of the geometry {N = positions, Di x Hi x Wi = kd x kh x kw, Do = Ho = Wo = 1}) + gode_col2im in its 3-D form, against
+    autograd through F.conv3d (the UCF video discriminator's first layer, models/mocogan.py:100, takes this path in the
+    generator step)."""
+    xin, k, st, pad = shape
+    N, Ci, Co = 3, 3, 64
+    gen = torch.Generator().manual_seed(sum(xin))
+    x = torch.randn(N, Ci, *xin, generator=gen, requires_grad=True)
+    w = torch.randn(Co, Ci, *k, generator=gen) * 0.1
+    y = F.conv3d(x, w, stride=st, padding=pad)
+    gy = torch.randn(y.shape, generator=gen)
+    y.backward(gy)
+    Do, Ho, Wo = y.shape[2:]
+    assert xin[0] == (Do - 1) * st[0] - 2 * pad[0] + k[0] and xin[1] == (Ho - 1) * st[1] - 2 * pad[1] + k[1]
+    lib = L.lib()
+    pos = N * Do * Ho * Wo
+    tg = make_geom(pos, Ci, Co, k, (1, 1, 1), k, (1, 1, 1), (0, 0, 0))
+    wd = w.cuda().contiguous()
+    wp = torch.empty(lib.gode_pack_size(C.byref(tg), L.DGRAD), device="cuda")
+    L.check(lib.gode_pack_weights(C.byref(tg), L.DGRAD, wd.data_ptr(), wp.data_ptr(), None, 0, stream()))
+    g0 = gy.permute(0, 2, 3, 4, 1).contiguous().cuda()                       # [N, Do, Ho, Wo, Co]
+    taps = k[0] * k[1] * k[2]
+    cols = torch.empty(pos * taps * Ci, device="cuda")
+    op = L.IgemmOp(g=tg, dir=L.DGRAD, act=L.ACT_NONE, epilogue=L.EPI_RAW, tile=0, src=g0.data_ptr(), wpack=wp.data_ptr(), out=cols.data_ptr())
+    ws = lib.gode_igemm_work_size(C.byref(op))
+    work = torch.empty(max(ws, 1), device="cuda")
+    op.work = work.data_ptr()
+    L.run_one(op, stream())
+    out = torch.full((N, xin[0], xin[1], xin[2], Ci), float("nan"), device="cuda")
+    c2i = L.Col2imOp(cols=cols.data_ptr(), out=out.data_ptr(), N=N, Hi=Ho, Wi=Wo, Ho=xin[1], Wo=xin[2], C=Ci, kh=k[1], kw=k[2],
+                     sh=st[1], sw=st[2], ph=pad[1], pw=pad[2], epilogue=L.EPI_RAW, Di=Do, Do=xin[0], kd=k[0], sd=st[0], pd=pad[0])
+    L.run_one(c2i, stream())
+    torch.cuda.synchronize()
+    want = x.grad.permute(0, 2, 3, 4, 1)
+    assert rel_err(out.cpu(), want) < 1e-5
+    c2i.Do = xin[0] + 1                                                        # not the transposed-convolution relation
+    with pytest.raises(RuntimeError):
+        L.run_one(c2i, stream())
+
+
 def _ode_setup(N, T, seed, prenet=True):
     from oracle.mocogan_ref import OdeRhs
     torch.manual_seed(seed)

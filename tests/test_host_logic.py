@@ -20,7 +20,7 @@ from oracle import mocogan_ref as M
 
 def test_library_loads_and_exports_every_declared_symbol():
     lib = L.lib()                      # also checks every op struct size against the compiled ABI
-    assert lib.gode_version() == 104
+    assert lib.gode_version() == 105
     hdr = open(os.path.join(REPO, "include", "gode.h")).read()
     declared = set(re.findall(r"\b(gode_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
