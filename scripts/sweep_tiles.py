@@ -65,7 +65,10 @@ for name, g in cases:
             work = torch.empty(max(ws, 1), device="cuda")
             op.work = work.data_ptr()
             rows = lib.gode_igemm_stats_rows(C.byref(op))
-            stats = torch.empty(rows * 2 * out_dims[-1] + 16, device="cuda")
+            # (full-K DGRAD geometries -- 1x1x1 output, kernel = input extent -- have taps * Ci statistics columns, not Ci)
+            fullk = d == L.DGRAD and (g.Do, g.Ho, g.Wo) == (1, 1, 1) and (g.Di, g.Hi, g.Wi) == (g.kd, g.kh, g.kw) and g.kd * g.kh * g.kw > 1
+            ncols = g.kd * g.kh * g.kw * g.Ci if fullk else out_dims[-1]
+            stats = torch.empty(max(rows, 1) * 2 * ncols + 16, device="cuda")
             op.stats = stats.data_ptr()
             st = stream_ptr()
             try:
