@@ -179,6 +179,45 @@ __global__ void __launch_bounds__(256) col2im_rows_kernel(const gode_col2im_op a
   }
 }
 
+// 3-D form, taps and strides known at compile time (the shape that matters: 4x4x4 taps, strides 1x2x2 -- the UCF video
+// discriminator's first layer): no divisions by run-time values, the <= 16 loads of a voxel are issued together.  Same tap
+// order (kd, kh, kw ascending) as the generic kernel below: bit-identical sums.
+template <int KD, int KH, int KW, int SD, int SH, int SW, int CC>
+__global__ void __launch_bounds__(256) col2im3d_fixed_kernel(const gode_col2im_op a) {
+  const uint32_t total = (uint32_t)a.N * a.Do * a.Ho * a.Wo;           // (< 2^31: checked by the launcher)
+  constexpr int KC = KD * KH * KW * CC;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t ow = i % (uint32_t)a.Wo; uint32_t t = i / (uint32_t)a.Wo;
+    const uint32_t oh = t % (uint32_t)a.Ho; t /= (uint32_t)a.Ho;
+    const uint32_t od = t % (uint32_t)a.Do, n = t / (uint32_t)a.Do;
+    float acc[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) acc[c] = 0.f;
+    const int d0 = ((int)od + a.pd) % SD, h0 = ((int)oh + a.ph) % SH, w0 = ((int)ow + a.pw) % SW;
+#pragma unroll
+    for (int jd = 0; jd < (KD + SD - 1) / SD; ++jd) {
+      const int kd = d0 + jd * SD, td = (int)od + a.pd - kd, id = td / SD;
+      if (kd >= KD || td < 0 || id >= a.Di) continue;
+#pragma unroll
+      for (int jh = 0; jh < (KH + SH - 1) / SH; ++jh) {
+        const int kh = h0 + jh * SH, th = (int)oh + a.ph - kh, ih = th / SH;
+        if (kh >= KH || th < 0 || ih >= a.Hi) continue;
+#pragma unroll
+        for (int jw = 0; jw < (KW + SW - 1) / SW; ++jw) {
+          const int kw = w0 + jw * SW, tw = (int)ow + a.pw - kw, iw = tw / SW;
+          if (kw >= KW || tw < 0 || iw >= a.Wi) continue;
+          const float* src = a.cols + ((((int64_t)n * a.Di + id) * a.Hi + ih) * a.Wi + iw) * KC + ((kd * KH + kh) * KW + kw) * CC;
+#pragma unroll
+          for (int c = 0; c < CC; ++c) acc[c] += src[c];
+        }
+      }
+    }
+    float* dst = a.out + (int64_t)i * CC;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) dst[c] = a.epilogue == GODE_EPI_TANH ? tanhf(acc[c]) : acc[c];
+  }
+}
+
 // 3-D form: one thread per output voxel, <= ceil(kd/sd) * ceil(kh/sh) * ceil(kw/sw) taps of C floats each, fixed tap order
 __global__ void __launch_bounds__(256) col2im3d_kernel(const gode_col2im_op a) {
   const int64_t total = (int64_t)a.N * a.Do * a.Ho * a.Wo;
@@ -215,7 +254,13 @@ extern "C" int gode_col2im(const gode_col2im_op* op, void* stream) {
   if (op->epilogue != GODE_EPI_RAW && op->epilogue != GODE_EPI_TANH) return GODE_E_ARG;
   if (op->kd > 0) {
     if (op->sd <= 0 || op->pd < 0 || op->Di <= 0 || op->Do != (op->Di - 1) * op->sd - 2 * op->pd + op->kd) return GODE_E_SHAPE;
-    int64_t nb = ((int64_t)op->N * op->Do * op->Ho * op->Wo + 255) / 256; if (nb > 16384) nb = 16384;
+    const int64_t voxels = (int64_t)op->N * op->Do * op->Ho * op->Wo;
+    int64_t nb = (voxels + 255) / 256; if (nb > 16384) nb = 16384;
+    if (op->kd == 4 && op->kh == 4 && op->kw == 4 && op->sd == 1 && op->sh == 2 && op->sw == 2 && op->C == 3 && voxels < (1ll << 31)) {
+      hipLaunchKernelGGL((col2im3d_fixed_kernel<4, 4, 4, 1, 2, 2, 3>), dim3((int)nb), dim3(256), 0, (hipStream_t)stream, *op);
+      GODE_LAUNCH_CHECK();
+      return 0;
+    }
     hipLaunchKernelGGL(col2im3d_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, *op);
     GODE_LAUNCH_CHECK();
     return 0;
