@@ -254,7 +254,7 @@ def _parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--train-steps", type=int, default=10, help="iterations for the G/D step timings")
+    ap.add_argument("--train-steps", type=int, default=30, help="iterations for the G/D step / iteration timings (10 until round 3: too few for a figure steady to 1 %)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="skip the HIP-graph replay timing of the training iteration")
     ap.add_argument("--no-live-traffic", action="store_true",
