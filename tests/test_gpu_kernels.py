@@ -428,17 +428,19 @@ def test_batched_weight_packing_brick_kernel_is_bitwise_the_elementwise_map():
         assert torch.equal(out, ref), (op.g.key(), op.dir)
 
 
-def test_operands_beyond_2_gib_take_the_register_staged_kernels():
+@pytest.mark.parametrize("N", [8200, 6200])
+def test_operands_beyond_2_gib_take_the_register_staged_kernels(N):
     """The LDS-DMA GEMM loops address their operands as raw buffers (32-bit byte offsets); an operand of 2 GiB or more makes
     gode_igemm / gode_wgrad fall back to the register-staged kernels.  Conv2d 64 -> 64 k3 p1 on 8,200 images of 32x32
     (2.0 GiB in, 2.0 GiB out): the first and the last images against the same op on those images alone (small tensors: the
     DMA kernels), and the weight gradient against the sum of the weight gradients of two halves."""
     lib = L.lib()
-    N, Cc, HW = 8200, 64, 32
+    Cc, HW = 64, 32
     g = make_geom(N, Cc, Cc, (1, HW, HW), (1, HW, HW), (1, 3, 3), (1, 1, 1), (0, 1, 1))
     gen = torch.Generator(device="cuda").manual_seed(3)
     x = torch.randn(N, 1, HW, HW, Cc, device="cuda", generator=gen)
-    assert x.numel() * 4 >= 2 ** 31
+    # N = 8200: 2.0 GiB, the fallback; N = 6200: 1.5 GiB, still the DMA kernels, with byte offsets above 2^30
+    assert (x.numel() * 4 >= 2 ** 31) == (N == 8200) and x.numel() * 4 > 2 ** 30
     w = torch.randn(Cc, Cc, 1, 3, 3, device="cuda", generator=gen) * 0.05
     wp = torch.empty(lib.gode_pack_size(C.byref(g), L.FPROP), device="cuda")
     L.check(lib.gode_pack_weights(C.byref(g), L.FPROP, w.data_ptr(), wp.data_ptr(), None, 0, stream()))
